@@ -1,0 +1,234 @@
+/*
+ * jaicov_neq.h -- C ABI of the MI355X normal-equation engine for JAICOV-style bundle adjustment.
+ *
+ * This is the drop-in boundary for ONE path of applied-geodesy/bundle-adjustment (JAICOV): the per-iteration
+ * Gauss-Newton / Levenberg-Marquardt inner loop of BundleAdjustment.estimateModel().  The reference has no FFI for
+ * this path (pure Java), so the boundary is defined here; every entry point names the reference code it replaces
+ * (paths relative to JAICOV/src/org/applied_geodesy/):
+ *
+ *   BA  = adjustment/bundle/BundleAdjustment.java
+ *   PDF = adjustment/bundle/derivation/PartialDerivativeFactory.java
+ *   NES = adjustment/NormalEquationSystem.java
+ *   MX  = adjustment/MathExtension.java
+ *   DOPG= adjustment/bundle/parameter/DirectlyObservedParameterGroup.java
+ *
+ * Conventions
+ *   - plain C, no torch / C++ types in any signature; all pointers are HOST pointers unless a name says "device".
+ *   - every function returns a jaicov_status (0 = ok).  Nothing throws across the boundary (BA:304-315 maps the
+ *     reference's exceptions to EstimationStateType codes the same way).
+ *   - one engine per BundleAdjustment, externally synchronised (the reference is single-threaded, BA:203 is
+ *     single-shot).
+ *   - matrices leave the engine in MTJ / LAPACK packed order, UPLO='U', column-major:
+ *         index(r,c) = r + c*(c+1)/2 ,  r <= c        (UpperSymmPackMatrix.getData(), MX:341-342)
+ *     order U = u + d: rows/columns 0..d-1 are the datum border (BA:493-635), unknowns follow (BA:776-781).
+ *   - a parameter that is FIXED in the reference (column == Integer.MAX_VALUE, UnknownParameter.java:27) carries
+ *     JAICOV_COL_FIXED here; free parameters carry their reference column (already shifted by d).
+ */
+#ifndef JAICOV_NEQ_H
+#define JAICOV_NEQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JAICOV_NEQ_ABI_VERSION 1
+#define JAICOV_COL_FIXED (-1)
+#define JAICOV_MAX_DIST_PER_CAMERA 20   /* distortion coefficients per camera the device kernels are built for */
+
+/* Status codes.  <0 : bad argument (reference: IllegalArgumentException, MX:352,363);
+ *                >0 : numerical failure (MatrixSingularException / MatrixNotSPDException, MX:350,361);
+ *                OOM and device errors are distinct (BA:370-375 OUT_OF_MEMORY).                         */
+typedef enum jaicov_status {
+    JAICOV_OK                 = 0,
+    JAICOV_ERR_BAD_ARGUMENT   = -1,
+    JAICOV_ERR_BAD_STATE      = -2,   /* call order violated (e.g. solve before build)                  */
+    JAICOV_ERR_UNSUPPORTED    = -3,
+    JAICOV_ERR_OUT_OF_MEMORY  = -4,
+    JAICOV_ERR_DEVICE         = -5,   /* HIP runtime error; text via jaicov_neq_last_error()            */
+    JAICOV_ERR_NO_DEVICE      = -6,   /* no gfx950 device / HIP runtime unusable: the engine never falls back to CPU */
+    JAICOV_ERR_SINGULAR       = 1,    /* factorisation hit a non-positive / zero pivot (info > 0)       */
+    JAICOV_ERR_NOT_FINITE     = 2     /* NaN/Inf in the step (BA:327-331)                               */
+} jaicov_status;
+
+/* Distortion coefficient kinds, in the reference's APPLICATION order (DistortionModel.Type ordinal,
+ * camera/distortion/DistortionModel.java:29-37; Camera.java:50 sorts by it).                            */
+typedef enum jaicov_dist_kind {
+    JAICOV_DIST_AFFINITY_CX   = 0,    /* AffinityShearDistortionModel Cx  (ASF:37-81)                   */
+    JAICOV_DIST_AFFINITY_CY   = 1,
+    JAICOV_DIST_TANGENTIAL_BX = 2,    /* TangentialDistortionModel Bx,By,Bi (TDF:39-134)                */
+    JAICOV_DIST_TANGENTIAL_BY = 3,
+    JAICOV_DIST_TANGENTIAL_BI = 4,
+    JAICOV_DIST_RADIAL_AI     = 5,    /* RadiallySymmetricDistortionModel Ai (RSF:39-90)                */
+    JAICOV_DIST_DISTANCE_DI   = 6     /* RadialDistanceDistortionModel Di (RDF:39-161)                  */
+} jaicov_dist_kind;
+
+/* Datum flags = which inner-constraint rows exist (RankDefect.java:119-130, BA:523-530 order).          */
+enum {
+    JAICOV_DATUM_TX = 1, JAICOV_DATUM_TY = 2, JAICOV_DATUM_TZ = 4,
+    JAICOV_DATUM_RX = 8, JAICOV_DATUM_RY = 16, JAICOV_DATUM_RZ = 32, JAICOV_DATUM_SCALE = 64
+};
+
+/*
+ * Immutable structure of one adjustment, flattened from the Java object graph after
+ * BA.prepareUnknownParameters() (BA:667-782) has numbered rows and columns.
+ *
+ * Parameter VALUES travel separately in one "slot" vector of length jaicov_neq_num_slots():
+ *     [ 3*n_points (X,Y,Z per point) | 3*n_cameras (x0,y0,c) | n_dist | 6*n_images (X0,Y0,Z0,omega,phi,kappa) ]
+ * Every parameter, free or fixed, owns a slot; free ones additionally own a column.
+ */
+typedef struct jaicov_problem_desc {
+    uint32_t struct_size;          /* sizeof(jaicov_problem_desc), checked                               */
+    int32_t  n_unknowns;           /* U = u + d, order of N (BA:791)                                     */
+    int32_t  rank_defect;          /* d (BA:776)                                                         */
+    int32_t  datum_flags;          /* JAICOV_DATUM_* of the FREE defects; popcount == rank_defect        */
+
+    int32_t  n_points, n_cameras, n_images, n_dist;
+    int32_t  n_image_points, n_image_blocks, n_scale_bars, n_direct_groups, n_direct_rows;
+
+    /* object points (ObjectCoordinate.java) */
+    const int32_t *point_col;      /* [3*n_points] column of X,Y,Z or JAICOV_COL_FIXED                   */
+    const uint8_t *point_datum;    /* [n_points]  ObjectCoordinate.isDatum()                             */
+
+    /* cameras (Camera.java, InteriorOrientation.java:60-82 order x0,y0,c) */
+    const int32_t *io_col;         /* [3*n_cameras]                                                      */
+    const double  *cam_r0;         /* [n_cameras] r0 of the radial / distance models (Camera.java:45)    */
+    const int32_t *cam_dist_begin; /* [n_cameras+1] range of this camera's coefficients in dist_*        */
+    const int32_t *dist_kind;      /* [n_dist] jaicov_dist_kind, per camera in application order         */
+    const int32_t *dist_order;     /* [n_dist] polynomial order i of Ai/Bi/Di (PolynomialCoefficient.java) */
+    const int32_t *dist_col;       /* [n_dist]                                                           */
+
+    /* images (Image.java, ExteriorOrientation.java:37-46 order X0,Y0,Z0,omega,phi,kappa) */
+    const int32_t *image_camera;   /* [n_images]                                                         */
+    const int32_t *eo_col;         /* [6*n_images]                                                       */
+
+    /* image points = ImageCoordinate observation groups, image-major (BA:670-693): rows 2k, 2k+1         */
+    const int32_t *ip_image;       /* [n_image_points]                                                   */
+    const int32_t *ip_point;       /* [n_image_points]                                                   */
+    const double  *ip_x, *ip_y;    /* observed xp, yp                                                    */
+    const double  *ip_var_x, *ip_var_y;   /* variances (ImageCoordinate.java:48-49)                      */
+    const double  *ip_rho;         /* correlation coefficient in (-1,1) (ImageCoordinate.java:40)        */
+
+    /* image blocks: contiguous ranges of image points of ONE image observed with a joint, fully
+     * populated dispersion (the largest W the reference's a10 contract can express).
+     * Image points outside every block are ordinary 2x2 groups.                                         */
+    const int32_t *blk_ip_begin;   /* [n_image_blocks+1] ranges must be disjoint and ascending           */
+    const int64_t *blk_disp_offset;/* [n_image_blocks] offset (in doubles) into blk_disp                 */
+    const double  *blk_disp;       /* row-major symmetric (2m x 2m) dispersion, rows x0,y0,x1,y1,...     */
+
+    /* scale bars (ScaleBar.java, PDF:210-283) */
+    const int32_t *sb_point_a, *sb_point_b;   /* [n_scale_bars]                                          */
+    const double  *sb_length, *sb_var;
+
+    /* directly observed parameter groups (DOPG, PDF:447-473) */
+    const int32_t *dg_row_begin;   /* [n_direct_groups+1]                                                */
+    const int32_t *dg_slot;        /* [n_direct_rows] slot of the referenced unknown parameter           */
+    const double  *dg_obs;         /* [n_direct_rows] observed value                                     */
+    const double  *dg_var;         /* [n_direct_rows] variance (diag of D when a dispersion is given)    */
+    const int64_t *dg_disp_offset; /* [n_direct_groups] offset into dg_disp, or -1 = diagonal (DOPG:71-78) */
+    const double  *dg_disp;        /* row-major symmetric (m x m) dispersion matrices (DOPG:49-61)       */
+} jaicov_problem_desc;
+
+typedef struct jaicov_engine_options {
+    uint32_t struct_size;
+    int32_t  device;               /* HIP device ordinal                                                 */
+    /* observation sharding: this engine accumulates only images [image_begin,image_end);
+     * scale bars, directly observed groups, datum, damping and V are applied by the rank with
+     * apply_shared != 0 ... after the reduction they are identical everywhere.  -1/-1 = all images.     */
+    int32_t  image_begin, image_end;
+    int32_t  apply_shared;
+    int32_t  assembly_mode;        /* 0 = structure-aware (default), 1 = densified MFMA contraction of image blocks */
+    int32_t  block_size;           /* factorisation block NB; 0 = default                                */
+    int32_t  reserved[8];
+} jaicov_engine_options;
+
+typedef struct jaicov_engine jaicov_engine;
+
+/* --- lifetime ---------------------------------------------------------------------------------------- */
+
+/* One-time upload of the immutable structure; inverts the dense dispersions to weights on the device
+ * (DOPG:82-86 does dpptrf+dpptri once and caches).  opts may be NULL.                                    */
+int  jaicov_neq_create(const jaicov_problem_desc *desc, const jaicov_engine_options *opts, jaicov_engine **out);
+void jaicov_neq_destroy(jaicov_engine *e);                      /* idempotent on NULL                    */
+const char *jaicov_neq_last_error(const jaicov_engine *e);      /* text of the last failure, never NULL  */
+int  jaicov_neq_abi_version(void);
+size_t jaicov_neq_num_slots(const jaicov_engine *e);
+size_t jaicov_neq_packed_length(const jaicov_engine *e);        /* U*(U+1)/2                             */
+
+/* --- parameter values (Parameter.value of every UnknownParameter) ------------------------------------ */
+int jaicov_neq_set_parameters(jaicov_engine *e, const double *slots, size_t n_slots);
+int jaicov_neq_get_parameters(jaicov_engine *e, double *slots, size_t n_slots);
+
+/* --- one pass of the loop body (BA:228-355) ---------------------------------------------------------- */
+
+/* replaces BA.createNormalEquation() (BA:789-834): residual + Jacobian rows (PDF:94-190,285-445 and the
+ * distortion factories), N += A'PA, n += A'Pw (PDF:475-505), datum rows (BA:493-635), LM damping
+ * N[c,c] *= (1+lambda) (BA:814-822), preconditioner V (BA:825-828), SIMULATION zeroes n (BA:830-831).
+ * = accumulate + (host all-reduce for multi-GPU) + finalize.                                             */
+int jaicov_neq_build(jaicov_engine *e, double sigma2apriori, double lambda, int simulation);
+int jaicov_neq_accumulate(jaicov_engine *e, double sigma2apriori);
+int jaicov_neq_finalize(jaicov_engine *e, double sigma2apriori, double lambda, int simulation);
+
+/* Device buffer holding this rank's partial normal equations between accumulate and finalize: a single
+ * contiguous array of *count doubles (row-major lower triangle storage of N followed by n).  A multi-GPU
+ * host sums it over ranks (ncclAllReduce, sum, double) -- SURVEY 8(e).                                   */
+int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count);
+
+/* replaces NES.applyPrecondition (NES:82-91) + MX.solve(N,n,numRows,invert) (MX:338-366) + the reverse
+ * preconditioning (BA:273,297).  dx_out[U] (border entries = Lagrange multipliers, as dspsv leaves them).
+ * invert != 0 keeps Qxx = K^-1 on the device (BA:274).                                                   */
+int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out);
+
+/* replaces BA.getOmega(dx) (BA:472-491): sum over groups of (w - A dx)' P (w - A dx) at the CURRENT
+ * (pre-update) parameters.                                                                               */
+int jaicov_neq_omega(jaicov_engine *e, double sigma2apriori, const double *dx, double *omega);
+
+/* replaces BA.updateUnknownParameters(dx) (BA:450-462): x[col] += dx[col] on the device copy of the slots;
+ * returns max |dx| over unknown columns.                                                                 */
+int jaicov_neq_update(jaicov_engine *e, const double *dx, double *max_abs_dx);
+
+/* --- results ----------------------------------------------------------------------------------------- */
+/* N (after finalize, before preconditioning) and n in packed 'U' order, for UpperSymmPackMatrix.getData() */
+int jaicov_neq_get_normal(jaicov_engine *e, double *N_packed, size_t len, double *n, size_t U);
+/* Qxx = K^-1 (BA:1177 getCofactorMatrix), packed 'U', order U.  Requires a solve with invert != 0.        */
+int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_t len);
+/* sub-matrix gather Q[idx[i], idx[j]] into a dense row-major k x k buffer (what MatlabResultWriter.java:210-221
+ * and DefaultResultWriter.java:126-155 read element-wise).                                               */
+int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx, int32_t k, double *out);
+/* compact residual/Jacobian rows of image point ip (debug / parity): w[2], A[2*(12+JAICOV_MAX_DIST_PER_CAMERA)]
+ * in local order X,Y,Z,x0,y0,c,X0,Y0,Z0,omega,phi,kappa,dist...                                          */
+int jaicov_neq_get_rows(jaicov_engine *e, int32_t ip_begin, int32_t ip_count, double *w, double *A);
+
+/* --- whole loop (BA.estimateModel, BA:203-387) ------------------------------------------------------- */
+typedef struct jaicov_estimate_options {
+    uint32_t struct_size;
+    int32_t  max_iterations;       /* DefaultValue.java:25 = 5000                                        */
+    int32_t  invert;               /* 0 = MatrixInversion.NONE, 1 = FULL (BA:65-70)                      */
+    int32_t  simulation;           /* EstimationType.SIMULATION (BA:830)                                 */
+    double   lambda0;              /* setLevenbergMarquardtDampingValue (BA:1189)                        */
+    double   sigma2apriori;        /* BA:98,641                                                          */
+} jaicov_estimate_options;
+
+typedef struct jaicov_estimate_result {
+    int32_t  state;                /* EstimationStateType id (adjustment/EstimationStateType.java:25-42):
+                                      1 ERROR_FREE_ESTIMATION, -1 INTERRUPT, -2 SINGULAR_MATRIX, -4 NO_CONVERGENCE,
+                                      -7 OUT_OF_MEMORY                                                    */
+    int32_t  iterations;
+    double   omega;
+    double   max_abs_dx;
+    double   final_lambda;
+    double   seconds_total, seconds_last_pass;
+} jaicov_estimate_result;
+
+int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_options *opts, jaicov_estimate_result *res);
+
+/* timing of the stages of the last pass in milliseconds (HIP events on the engine stream):
+ * [0] rows  [1] assembly  [2] finalize  [3] factorisation  [4] solve  [5] inverse  [6] omega  [7] total  */
+int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAICOV_NEQ_H */
