@@ -1,0 +1,456 @@
+// Normal-equation assembly N += A'PA, n += A'Pw (PDF:475-505 stackNormalEquationSystem) from the compact rows,
+// structure-aware: the shared camera/EO blocks of an image are reduced on chip (LDS) before they touch HBM, only the
+// point-indexed blocks go out as fp64 atomics.  N is row-major LOWER (== UPLO='U' column-major).  gfx950 only.
+#include "ba_kernels.h"
+
+namespace jaicov {
+
+// shared local column c (0..kc) -> local row id l in the rows buffer, and its global column
+//   c: 0..2 = x0,y0,c ; 3..8 = X0,Y0,Z0,omega,phi,kappa ; 9.. = distortion coefficients
+__device__ __forceinline__ int shared_local(int c) { return c < 3 ? 3 + c : (c < 9 ? 6 + (c - 3) : 12 + (c - 9)); }
+__device__ __forceinline__ int shared_col(const DevProblem &p, int img, int cam, int jb, int c) {
+    return c < 3 ? p.io_col[3 * cam + c] : (c < 9 ? p.eo_col[6 * img + (c - 3)] : p.dist_col[jb + (c - 9)]);
+}
+
+// 2x2 weight of an ordinary image point (PDF:296-319): returns p00, p01, p11
+__device__ __forceinline__ void weight2x2(const DevProblem &p, int ip, double sigma2, double &p00, double &p01,
+                                          double &p11) {
+    const double vx = p.ip_var_x[ip], vy = p.ip_var_y[ip], rho = p.ip_rho[ip];
+    if (rho == 0) {
+        p00 = sigma2 / vx; p11 = sigma2 / vy; p01 = 0.0;
+    } else {
+        const double invDet = sigma2 / ((1.0 - rho * rho) * vx * vy);
+        p00 = invDet * vy;
+        p11 = invDet * vx;
+        p01 = -invDet * rho * sqrt(vx * vy);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ordinary (2x2 / diagonal) image points: one workgroup per segment of <= 256 points of one image
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void assemble_small_kernel(DevProblem p, const int32_t *__restrict__ seg_begin,
+                                                             const int32_t *__restrict__ seg_end,
+                                                             const double *__restrict__ rowsA,
+                                                             const double *__restrict__ rowsW, double sigma2,
+                                                             double *__restrict__ N, double *__restrict__ n) {
+    __shared__ double As[2 * SEG * KC_LD];   // [obs row k][c], c = kc holds w
+    __shared__ double Ps[SEG * 3];
+    __shared__ int cols[KC_MAX];
+    const int tid = threadIdx.x;
+    const int b = seg_begin[blockIdx.x], e = seg_end[blockIdx.x], cnt = e - b;
+    const long S = p.n_ip;
+    const int img = p.ip_image[b], cam = p.image_camera[img];
+    const int jb = p.cam_dist_begin[cam], nd = p.cam_dist_begin[cam + 1] - jb;
+    const int kc = 9 + nd;
+    if (tid < kc) cols[tid] = shared_col(p, img, cam, jb, tid);
+    // stage the shared sub-rows
+    for (int idx = tid; idx < 2 * cnt * (kc + 1); idx += 256) {
+        const int c = idx / (2 * cnt), k = idx - c * (2 * cnt);      // k = 2*o + r ... coalesce over o below
+        const int r = k / cnt, o = k - r * cnt;
+        const double v = (c < kc) ? rowsA[(long)(2 * shared_local(c) + r) * S + b + o] : rowsW[(long)r * S + b + o];
+        As[(2 * o + r) * KC_LD + c] = v;
+    }
+    if (tid < cnt) {
+        double p00, p01, p11;
+        weight2x2(p, b + tid, sigma2, p00, p01, p11);
+        Ps[3 * tid] = p00; Ps[3 * tid + 1] = p01; Ps[3 * tid + 2] = p11;
+    }
+    __syncthreads();
+    // ---- per observation: point blocks ---------------------------------------------------------------------
+    if (tid < cnt) {
+        const int ip = b + tid, pt = p.ip_point[ip];
+        const double p00 = Ps[3 * tid], p01 = Ps[3 * tid + 1], p11 = Ps[3 * tid + 2];
+        double ap[2][3], g[2][3];      // g = P * A_p
+        int pc[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            ap[0][a] = rowsA[(long)(2 * a) * S + ip];
+            ap[1][a] = rowsA[(long)(2 * a + 1) * S + ip];
+            g[0][a] = p00 * ap[0][a] + p01 * ap[1][a];
+            g[1][a] = p01 * ap[0][a] + p11 * ap[1][a];
+            pc[a] = p.point_col[3 * pt + a];
+        }
+        const double w0 = As[(2 * tid) * KC_LD + kc], w1 = As[(2 * tid + 1) * KC_LD + kc];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            if (pc[a] < 0) continue;
+            unsafeAtomicAdd(n + pc[a], g[0][a] * w0 + g[1][a] * w1);
+#pragma unroll
+            for (int c2 = 0; c2 <= a; c2++)
+                if (pc[c2] >= 0) nadd(N, p.ld, pc[a], pc[c2], g[0][a] * ap[0][c2] + g[1][a] * ap[1][c2]);
+        }
+        for (int c = 0; c < kc; c++) {
+            const int gc = cols[c];
+            if (gc < 0) continue;
+            const double a0 = As[(2 * tid) * KC_LD + c], a1 = As[(2 * tid + 1) * KC_LD + c];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                if (pc[a] >= 0) nadd(N, p.ld, gc, pc[a], g[0][a] * a0 + g[1][a] * a1);
+        }
+    }
+    // ---- shared block: S[a][b] = sum_o A_o[:,a]' P_o A_o[:,b] (b <= a), and n_c ----------------------------
+    const int nent = kc * (kc + 1) / 2 + kc;
+    for (int ent = tid; ent < nent; ent += 256) {
+        int a, bb;
+        if (ent < kc) { a = ent; bb = kc; }                      // n entries: column kc = w
+        else {
+            const int t = ent - kc;
+            a = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((a + 1) * (a + 2) / 2 <= t) ++a;
+            while (a * (a + 1) / 2 > t) --a;
+            bb = t - a * (a + 1) / 2;
+        }
+        const int ga = cols[a];
+        const int gb = bb < kc ? cols[bb] : 0;
+        if (ga < 0 || gb < 0) continue;
+        double s = 0.0;
+        for (int o = 0; o < cnt; o++) {
+            const double a0 = As[(2 * o) * KC_LD + a], a1 = As[(2 * o + 1) * KC_LD + a];
+            const double b0 = As[(2 * o) * KC_LD + bb], b1 = As[(2 * o + 1) * KC_LD + bb];
+            const double p00 = Ps[3 * o], p01 = Ps[3 * o + 1], p11 = Ps[3 * o + 2];
+            s += a0 * (p00 * b0 + p01 * b1) + a1 * (p01 * b0 + p11 * b1);
+        }
+        if (bb == kc) unsafeAtomicAdd(n + ga, s);
+        else nadd(N, p.ld, ga, gb, s);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// image blocks (jointly dispersed image points of one image; weight = sigma2 * Dinv, Dinv dense m x m)
+// ---------------------------------------------------------------------------------------------------------------
+// B1: T = Dinv * [A_c | w]   (m x (kc+1)); thread = row r, P streamed once (symmetric: column r == row r, coalesced)
+__global__ __launch_bounds__(128) void blk_T_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                    const double *__restrict__ rowsA, const double *__restrict__ rowsW,
+                                                    double *__restrict__ T) {
+    __shared__ double Ac[64 * KC_LD];
+    const int g = blk_list[blockIdx.y];
+    const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
+    const int r = blockIdx.x * 128 + threadIdx.x;
+    if (blockIdx.x * 128 >= m) return;
+    const long S = p.n_ip;
+    const int img = p.ip_image[ipb], cam = p.image_camera[img];
+    const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
+    const double *P = p.blk_w + p.blk_w_offset[g];
+    double acc[KC_LD];
+#pragma unroll
+    for (int c = 0; c < KC_LD; c++) acc[c] = 0.0;
+    for (int k0 = 0; k0 < m; k0 += 64) {
+        const int kn = min(64, m - k0);
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < kn * (kc + 1); idx += 128) {
+            const int c = idx / kn, kk = idx - c * kn;
+            const int k = k0 + kk, o = k >> 1, rr = k & 1;
+            Ac[kk * KC_LD + c] = (c < kc) ? rowsA[(long)(2 * shared_local(c) + rr) * S + ipb + o]
+                                          : rowsW[(long)rr * S + ipb + o];
+        }
+        __syncthreads();
+        if (r < m) {
+            for (int kk = 0; kk < kn; kk++) {
+                const double pk = P[(long)(k0 + kk) * m + r];
+#pragma unroll
+                for (int c = 0; c < KC_LD; c++) acc[c] += pk * Ac[kk * KC_LD + c];
+            }
+        }
+    }
+    if (r < m) {
+        double *out = T + ((long)2 * ipb + r) * KC_LD;
+#pragma unroll
+        for (int c = 0; c < KC_LD; c++) out[c] = acc[c];
+    }
+}
+
+// B2: shared block S_cc = A_c' T_c, n_c = A_c' T_w  -> atomics (one workgroup per block)
+__global__ __launch_bounds__(256) void blk_cc_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                     const double *__restrict__ rowsA, const double *__restrict__ T,
+                                                     double sigma2, double *__restrict__ N, double *__restrict__ n) {
+    __shared__ int cols[KC_MAX];
+    const int g = blk_list[blockIdx.x];
+    const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
+    const long S = p.n_ip;
+    const int img = p.ip_image[ipb], cam = p.image_camera[img];
+    const int jb = p.cam_dist_begin[cam], kc = 9 + p.cam_dist_begin[cam + 1] - jb;
+    if (threadIdx.x < kc) cols[threadIdx.x] = shared_col(p, img, cam, jb, threadIdx.x);
+    __syncthreads();
+    const int nent = kc * (kc + 1);   // a in [0,kc), b in [0,kc] (b == kc -> n)
+    for (int ent = threadIdx.x; ent < nent; ent += 256) {
+        const int a = ent / (kc + 1), bb = ent - a * (kc + 1);
+        if (bb < kc && bb > a) continue;
+        const int ga = cols[a], gb = bb < kc ? cols[bb] : 0;
+        if (ga < 0 || gb < 0) continue;
+        const double *ra = rowsA + (long)(2 * shared_local(a)) * S + ipb;
+        const double *tb = T + (long)2 * ipb * KC_LD + bb;
+        double s = 0.0;
+        for (int o = 0; o < m / 2; o++)
+            s += ra[o] * tb[(long)(2 * o) * KC_LD] + ra[S + o] * tb[(long)(2 * o + 1) * KC_LD];
+        s *= sigma2;
+        if (bb == kc) unsafeAtomicAdd(n + ga, s);
+        else nadd(N, p.ld, ga, gb, s);
+    }
+}
+
+// B3: point x shared blocks and n[point]: thread per (block image point, shared column c <= kc)
+__global__ __launch_bounds__(256) void blk_pc_kernel(DevProblem p, const int32_t *__restrict__ blk_of_ip,
+                                                     const int32_t *__restrict__ ip_list, int n_list,
+                                                     const double *__restrict__ rowsA, const double *__restrict__ T,
+                                                     double sigma2, double *__restrict__ N, double *__restrict__ n) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int li = (int)(gid / KC_LD), c = (int)(gid - (long)li * KC_LD);
+    if (li >= n_list) return;
+    const int ip = ip_list[li];
+    (void)blk_of_ip;
+    const long S = p.n_ip;
+    const int img = p.ip_image[ip], cam = p.image_camera[img], pt = p.ip_point[ip];
+    const int jb = p.cam_dist_begin[cam], kc = 9 + p.cam_dist_begin[cam + 1] - jb;
+    if (c > kc) return;
+    const int gc = c < kc ? shared_col(p, img, cam, jb, c) : 0;
+    if (gc < 0) return;
+    const double t0 = T[((long)2 * ip) * KC_LD + c], t1 = T[((long)2 * ip + 1) * KC_LD + c];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int pc = p.point_col[3 * pt + a];
+        if (pc < 0) continue;
+        const double v = sigma2 * (rowsA[(long)(2 * a) * S + ip] * t0 + rowsA[(long)(2 * a + 1) * S + ip] * t1);
+        if (c == kc) unsafeAtomicAdd(n + pc, v);
+        else nadd(N, p.ld, gc, pc, v);
+    }
+}
+
+// B4: point x point blocks: N[pt_p, pt_q] += A_p' Dinv[rows p, rows q] A_q * sigma2, q <= p within the block.
+// grid (ceil(mp/16), ceil(mp/16), n_blocks_in_list), block 16x16: x = q, y = p
+__global__ __launch_bounds__(256) void blk_pp_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                     const double *__restrict__ rowsA, double sigma2,
+                                                     double *__restrict__ N) {
+    if (blockIdx.x > blockIdx.y) return;
+    const int g = blk_list[blockIdx.z];
+    const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb, m = 2 * mp;
+    const int q = blockIdx.x * 16 + threadIdx.x, pp = blockIdx.y * 16 + threadIdx.y;
+    if (pp >= mp || q > pp) return;
+    const long S = p.n_ip;
+    const double *P = p.blk_w + p.blk_w_offset[g];
+    const double P00 = P[(long)(2 * pp) * m + 2 * q], P01 = P[(long)(2 * pp) * m + 2 * q + 1];
+    const double P10 = P[(long)(2 * pp + 1) * m + 2 * q], P11 = P[(long)(2 * pp + 1) * m + 2 * q + 1];
+    const int ipp = ipb + pp, ipq = ipb + q;
+    const int ptp = p.ip_point[ipp], ptq = p.ip_point[ipq];
+    double gq[2][3];   // Dinv_pq * A_q
+    int cq[3], cp[3];
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const double a0 = rowsA[(long)(2 * b) * S + ipq], a1 = rowsA[(long)(2 * b + 1) * S + ipq];
+        gq[0][b] = P00 * a0 + P01 * a1;
+        gq[1][b] = P10 * a0 + P11 * a1;
+        cq[b] = p.point_col[3 * ptq + b];
+        cp[b] = p.point_col[3 * ptp + b];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        if (cp[a] < 0) continue;
+        const double a0 = rowsA[(long)(2 * a) * S + ipp], a1 = rowsA[(long)(2 * a + 1) * S + ipp];
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            if (cq[b] < 0) continue;
+            if (pp == q && b > a) continue;      // diagonal pair: lower triangle of the symmetric 3x3 only
+            nadd(N, p.ld, cp[a], cq[b], sigma2 * (a0 * gq[0][b] + a1 * gq[1][b]));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// scale bars (PDF:210-283): one thread each
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void scalebar_kernel(DevProblem p, const double *__restrict__ vals, double sigma2, double *N, double *n,
+                                const double *dx, double *omega) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.n_sb) return;
+    const int pa = p.sb_a[s], pb = p.sb_b[s];
+    const double *a = vals + 3 * pa, *b = vals + 3 * pb;
+    const double dX = b[0] - a[0], dY = b[1] - a[1], dZ = b[2] - a[2];
+    const double len = sqrt(dX * dX + dY * dY + dZ * dZ);
+    const double ev[6] = {-dX / len, -dY / len, -dZ / len, dX / len, dY / len, dZ / len};
+    const double P = sigma2 / p.sb_var[s];
+    const double w = p.sb_len[s] - len;
+    int col[6];
+    for (int t = 0; t < 6; t++) col[t] = t < 3 ? p.point_col[3 * pa + t] : p.point_col[3 * pb + t - 3];
+    if (dx) {   // omega mode (BA:480-488)
+        double v = w;
+        for (int t = 0; t < 6; t++)
+            if (col[t] >= 0) v -= ev[t] * dx[col[t]];
+        unsafeAtomicAdd(omega, v * P * v);
+        return;
+    }
+    for (int t = 0; t < 6; t++) {
+        if (col[t] < 0) continue;
+        unsafeAtomicAdd(n + col[t], ev[t] * P * w);
+        for (int u = 0; u <= t; u++)
+            if (col[u] >= 0) nadd(N, p.ld, col[t], col[u], ev[t] * P * ev[u]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// directly observed groups (PDF:447-473): A is a selection matrix -> N[cols,cols] += P, n[cols] += P w
+// one workgroup per group
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void direct_kernel(DevProblem p, const double *__restrict__ vals, double sigma2,
+                                                     double *N, double *n, const double *dx, double *omega) {
+    const int g = blockIdx.x;
+    const int b = p.dg_row_begin[g], m = p.dg_row_begin[g + 1] - b;
+    const long woff = p.dg_w_offset[g];
+    const double *W = woff >= 0 ? p.dg_w + woff : nullptr;
+    __shared__ double red[256];
+    double om = 0.0;
+    for (int r = threadIdx.x; r < m; r += 256) {
+        const int slot_r = p.dg_slot[b + r], cr = p.slot_col[slot_r];
+        double pw = 0.0;    // (P v)[r], v = w - A dx
+        if (W) {
+            for (int c = 0; c < m; c++) {
+                const int sc = p.dg_slot[b + c], cc = p.slot_col[sc];
+                double vc = p.dg_obs[b + c] - vals[sc];
+                if (dx && cc >= 0) vc -= dx[cc];
+                pw += sigma2 * W[(long)r * m + c] * vc;
+            }
+        } else {
+            double vr = p.dg_obs[b + r] - vals[slot_r];
+            if (dx && cr >= 0) vr -= dx[cr];
+            pw = sigma2 / p.dg_var[b + r] * vr;
+        }
+        if (dx) {
+            double vr = p.dg_obs[b + r] - vals[slot_r];
+            if (cr >= 0) vr -= dx[cr];
+            om += vr * pw;
+        } else if (cr >= 0) {
+            unsafeAtomicAdd(n + cr, pw);
+            if (W) {
+                for (int c = 0; c <= r; c++) {
+                    const int cc = p.slot_col[p.dg_slot[b + c]];
+                    if (cc >= 0) nadd(N, p.ld, cr, cc, sigma2 * W[(long)r * m + c]);
+                }
+            } else {
+                nadd(N, p.ld, cr, cr, sigma2 / p.dg_var[b + r]);
+            }
+        }
+    }
+    if (dx) {
+        red[threadIdx.x] = om;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) unsafeAtomicAdd(omega, red[0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// omega (BA:472-491): v = w - A dx per image point; ordinary points reduce v'Pv directly, block points park v
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void omega_points_kernel(DevProblem p, const uint8_t *__restrict__ in_block,
+                                                           int ip0, int count, const double *__restrict__ rowsA,
+                                                           const double *__restrict__ rowsW,
+                                                           const double *__restrict__ dx, double sigma2,
+                                                           double *__restrict__ vbuf, double *omega) {
+    __shared__ double red[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double om = 0.0;
+    if (i < count) {
+        const int ip = ip0 + i;
+        const long S = p.n_ip;
+        const int img = p.ip_image[ip], cam = p.image_camera[img], pt = p.ip_point[ip];
+        const int jb = p.cam_dist_begin[cam], nd = p.cam_dist_begin[cam + 1] - jb;
+        double v0 = rowsW[ip], v1 = rowsW[S + ip];
+        for (int l = 0; l < 12 + nd; l++) {
+            const int col = l < 3 ? p.point_col[3 * pt + l]
+                                  : (l < 6 ? p.io_col[3 * cam + l - 3] : (l < 12 ? p.eo_col[6 * img + l - 6] : p.dist_col[jb + l - 12]));
+            if (col < 0) continue;
+            const double d = dx[col];
+            v0 -= rowsA[(long)(2 * l) * S + ip] * d;
+            v1 -= rowsA[(long)(2 * l + 1) * S + ip] * d;
+        }
+        if (in_block[ip]) {
+            vbuf[2 * (long)ip] = v0;
+            vbuf[2 * (long)ip + 1] = v1;
+        } else {
+            double p00, p01, p11;
+            weight2x2(p, ip, sigma2, p00, p01, p11);
+            om = v0 * (p00 * v0 + p01 * v1) + v1 * (p01 * v0 + p11 * v1);
+        }
+    }
+    red[threadIdx.x] = om;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && red[0] != 0.0) unsafeAtomicAdd(omega, red[0]);
+}
+
+// omega of an image block: sigma2 * v' Dinv v ; grid (ceil(m/256), n_list)
+__global__ __launch_bounds__(256) void omega_block_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                          const double *__restrict__ vbuf, double sigma2,
+                                                          double *omega) {
+    __shared__ double red[256];
+    const int g = blk_list[blockIdx.y];
+    const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const double *P = p.blk_w + p.blk_w_offset[g];
+    const double *v = vbuf + 2 * (long)ipb;
+    double s = 0.0;
+    if (r < m) {
+        for (int k = 0; k < m; k++) s += P[(long)k * m + r] * v[k];
+        s *= v[r] * sigma2;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int t = 128; t > 0; t >>= 1) {
+        if (threadIdx.x < t) red[threadIdx.x] += red[threadIdx.x + t];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) unsafeAtomicAdd(omega, red[0]);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host-callable launchers
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t launch_assemble_small(hipStream_t s, const DevProblem &p, const int32_t *seg_begin, const int32_t *seg_end,
+                                 int n_seg, const double *rowsA, const double *rowsW, double sigma2, double *N,
+                                 double *n) {
+    if (n_seg <= 0) return hipSuccess;
+    hipLaunchKernelGGL(assemble_small_kernel, dim3(n_seg), dim3(256), 0, s, p, seg_begin, seg_end, rowsA, rowsW, sigma2,
+                       N, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
+                                  const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
+                                  double *T, double sigma2, double *N, double *n) {
+    if (n_list <= 0) return hipSuccess;
+    hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + 127) / 128, n_list), dim3(128), 0, s, p, blk_list, rowsA, rowsW, T);
+    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, T, sigma2, N, n);
+    const long tot = (long)n_ip_list * KC_LD;
+    hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
+                       ip_list, n_ip_list, rowsA, T, sigma2, N, n);
+    const int mp = max_m / 2, tq = (mp + 15) / 16;
+    hipLaunchKernelGGL(blk_pp_kernel, dim3(tq, tq, n_list), dim3(16, 16), 0, s, p, blk_list, rowsA, sigma2, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_shared_groups(hipStream_t s, const DevProblem &p, const double *vals, double sigma2, double *N,
+                                double *n, const double *dx, double *omega) {
+    if (p.n_sb > 0)
+        hipLaunchKernelGGL(scalebar_kernel, dim3((p.n_sb + 63) / 64), dim3(64), 0, s, p, vals, sigma2, N, n, dx, omega);
+    if (p.n_dg > 0) hipLaunchKernelGGL(direct_kernel, dim3(p.n_dg), dim3(256), 0, s, p, vals, sigma2, N, n, dx, omega);
+    return hipGetLastError();
+}
+
+hipError_t launch_omega(hipStream_t s, const DevProblem &p, const uint8_t *in_block, int ip0, int count,
+                        const int32_t *blk_list, int n_list, int max_m, const double *rowsA, const double *rowsW,
+                        const double *dx, double sigma2, double *vbuf, double *omega) {
+    if (count > 0)
+        hipLaunchKernelGGL(omega_points_kernel, dim3((count + 255) / 256), dim3(256), 0, s, p, in_block, ip0, count,
+                           rowsA, rowsW, dx, sigma2, vbuf, omega);
+    if (n_list > 0)
+        hipLaunchKernelGGL(omega_block_kernel, dim3((max_m + 255) / 256, n_list), dim3(256), 0, s, p, blk_list, vbuf,
+                           sigma2, omega);
+    return hipGetLastError();
+}
+
+}  // namespace jaicov

@@ -1,0 +1,58 @@
+// Bundle-adjustment device kernels: residual/Jacobian rows, normal-equation assembly, omega.  gfx950 only.
+// Reference arithmetic (paths relative to JAICOV/src/org/applied_geodesy/adjustment/bundle/derivation/):
+//   PartialDerivativeFactory.java (PDF), DistortionModelFactory.java (DMF), RadiallySymmetric.. (RSF),
+//   Tangential.. (TDF), AffinityShear.. (ASF), RadialDistance..DistortionModelFactory.java (RDF).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/jaicov_neq.h"
+
+namespace jaicov {
+
+constexpr int MAXD = JAICOV_MAX_DIST_PER_CAMERA;   // 20
+constexpr int KROW = 12 + MAXD;                    // local row layout: X,Y,Z,x0,y0,c,X0,Y0,Z0,omega,phi,kappa,dist..
+constexpr int KC_MAX = 9 + MAXD;                   // shared (camera + EO) local columns: io(3), eo(6), dist
+constexpr int KC_LD = KC_MAX + 1;                  // + the misclosure column in T = P [A_c | w]
+constexpr int SEG = 256;                           // image points per assembly segment
+
+// Device-side view of jaicov_problem_desc (device pointers) + derived tables
+struct DevProblem {
+    int U, Upad, d, n_points, n_cameras, n_images, n_dist, n_ip, n_blocks, n_sb, n_dg, n_dg_rows, n_slots;
+    long ld;
+    const int32_t *point_col, *io_col, *cam_dist_begin, *dist_kind, *dist_order, *dist_col, *image_camera, *eo_col;
+    const double *cam_r0;
+    const int32_t *ip_image, *ip_point;
+    const double *ip_x, *ip_y, *ip_var_x, *ip_var_y, *ip_rho;
+    const int32_t *blk_ip_begin;       // [n_blocks+1]
+    const int64_t *blk_w_offset;       // [n_blocks] offset of the block's D^-1 (m x m row-major) in blk_w
+    const double *blk_w;
+    const int32_t *sb_a, *sb_b;
+    const double *sb_len, *sb_var;
+    const int32_t *dg_row_begin, *dg_slot;
+    const double *dg_obs, *dg_var;
+    const int64_t *dg_w_offset;        // -1 = diagonal
+    const double *dg_w;                // D^-1 of dense groups
+    const int32_t *slot_col;           // [n_slots]
+};
+
+// ---- slot layout ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int slot_io(const DevProblem &p, int c) { return 3 * p.n_points + 3 * c; }
+__device__ __forceinline__ int slot_dist(const DevProblem &p, int j) { return 3 * p.n_points + 3 * p.n_cameras + j; }
+__device__ __forceinline__ int slot_eo(const DevProblem &p, int i) {
+    return 3 * p.n_points + 3 * p.n_cameras + p.n_dist + 6 * i;
+}
+
+__device__ __forceinline__ double ipow(double b, int e) {   // Math.pow(double,int) for small e >= 0
+    double r = 1.0;
+    for (int i = 0; i < e; i++) r *= b;
+    return r;
+}
+
+// lower-storage atomic add: N[max(r,c)][min(r,c)]
+__device__ __forceinline__ void nadd(double *N, long ld, int r, int c, double v) {
+    const int hi = r > c ? r : c, lo = r > c ? c : r;
+    unsafeAtomicAdd(N + (long)hi * ld + lo, v);
+}
+
+}  // namespace jaicov

@@ -1,0 +1,39 @@
+// Dense fp64 SPD machinery on the device: blocked Cholesky, multi-rhs substitution, triangular inverse, L^-T L^-1.
+// Storage: row-major, LOWER triangle, order n (multiple of 128), leading dimension ld.  The same memory read
+// column-major is LAPACK's UPLO='U' -- which is how MTJ's UpperSymmPackMatrix (packed) maps onto it.
+// Replaces the arithmetic of MathExtension.solve / MathExtension.inv (MathExtension.java:239-264,304-324,338-366),
+// i.e. netlib dppsv/dpptrf/dpptri and (through the bordered formulation in engine.hip) dspsv/dsptri.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jaicov {
+
+constexpr int DENSE_NB = 128;      // diagonal block handled by one workgroup in LDS
+constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry at once
+
+struct DenseSolver {
+    hipStream_t stream = nullptr;
+    int n = 0;                 // padded order, multiple of 128
+    long ld = 0;
+    double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
+    double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
+    double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse
+    double *Q = nullptr;       // n x ld : (L L')^-1 (lower tiles valid; symmetrize() fills the rest)
+    double *T = nullptr;       // workspace of the recursive triangular inverse
+    size_t T_elems = 0;
+    int *d_info = nullptr;     // first failing pivot (1-based), 0 = ok
+    bool owns = false;
+
+    hipError_t init(hipStream_t s, int n_padded, bool with_inverse);
+    void release();
+    hipError_t potrf();                                     // L <- chol(L); info via fetch_info()
+    hipError_t backsolve(const double *Y, double *Ywork, double *X, int nrhs);   // solves L' X = Y, rows are vectors
+    hipError_t forwardsolve(double *Ywork, double *Z, int nrhs);   // solves L Z = Y (rows are vectors; Ywork is clobbered)
+    hipError_t trtri();                                     // W <- L^-1
+    hipError_t lauum();                                     // Q <- W' W (lower tiles)
+    hipError_t symmetrize(double *M);                       // copy lower -> upper
+    int fetch_info();                                       // synchronises the stream
+};
+
+}  // namespace jaicov

@@ -1,0 +1,284 @@
+// Dense fp64 SPD solver kernels + drivers (see dense.h).  gfx950 only.
+#include "dense.h"
+
+#include <math.h>
+#include <stdio.h>
+
+#include "gemm_f64.h"
+
+namespace jaicov {
+
+#define HIPCHK(x)                                  \
+    do {                                           \
+        hipError_t _e = (x);                       \
+        if (_e != hipSuccess) return _e;           \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Diagonal block: Cholesky of a 128x128 SPD block held in LDS by one workgroup, plus the inverse of its factor.
+// A (global, lower part) <- L ; inv_out (128x128 row-major, zeros above the diagonal) <- L^-1.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DP = 129;  // padded LDS row (conflict-free column walks)
+
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, double *inv_out, int *info, int blk) {
+    __shared__ double S[128 * DP];
+    __shared__ double xd[128];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        S[r * DP + c] = (c <= r) ? A[(long)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < 128; j++) {
+        if (tid == 0) {
+            double d = S[j * DP + j];
+            if (!(d > 0.0)) {   // not positive definite (also catches NaN): MatrixNotSPDException / info > 0
+                atomicCAS(info, 0, blk * 128 + j + 1);
+                d = 1.0;
+            }
+            S[j * DP + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double ljj = S[j * DP + j];
+        for (int i = j + 1 + tid; i < 128; i += 256) S[i * DP + j] /= ljj;
+        __syncthreads();
+        for (int i = j + 1 + (tid >> 4); i < 128; i += 16) {
+            const double lij = S[i * DP + j];
+            for (int k = j + 1 + (tid & 15); k <= i; k += 16) S[i * DP + k] -= lij * S[k * DP + j];
+        }
+        __syncthreads();
+    }
+    // write the factor back (lower part only)
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        if (c <= r) A[(long)r * ld + c] = S[r * DP + c];
+    }
+    // X = L^-1, column j by thread j; X[i][j] (i > j) is parked at S[j][i] (strict upper part), X[j][j] in xd
+    if (tid < 128) {
+        const int j = tid;
+        const double xjj = 1.0 / S[j * DP + j];
+        xd[j] = xjj;
+        for (int i = j + 1; i < 128; i++) {
+            double s = S[i * DP + j] * xjj;
+            for (int k = j + 1; k < i; k++) s += S[i * DP + k] * S[j * DP + k];
+            S[j * DP + i] = -s / S[i * DP + i];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 128 * 128; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        inv_out[idx] = (c < r) ? S[c * DP + r] : (c == r ? xd[r] : 0.0);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// substitution steps (nrhs <= 8 vectors stored as rows of Y / X, length n)
+// ---------------------------------------------------------------------------------------------------------------
+// backward, step k: x_k = invL_kk' y_k ; y_b -= L[k][b]' x_k for every block b < k.   grid = k+1, block = 128
+__global__ __launch_bounds__(128) void backsub_step_kernel(const double *L, long ld, const double *invd_k, double *Y,
+                                                           double *X, int n, int k, int nrhs) {
+    __shared__ double yk[DENSE_MAX_RHS][128];
+    __shared__ double xk[DENSE_MAX_RHS][128];
+    const int t = threadIdx.x, b = blockIdx.x;
+    for (int q = 0; q < nrhs; q++) yk[q][t] = Y[(long)q * n + k * 128 + t];
+    __syncthreads();
+    for (int q = 0; q < nrhs; q++) {
+        double s = 0.0;
+        for (int r = t; r < 128; r++) s += invd_k[r * 128 + t] * yk[q][r];
+        xk[q][t] = s;
+    }
+    __syncthreads();
+    if (b == k) {
+        for (int q = 0; q < nrhs; q++) X[(long)q * n + k * 128 + t] = xk[q][t];
+    } else {
+        double acc[DENSE_MAX_RHS];
+#pragma unroll
+        for (int q = 0; q < DENSE_MAX_RHS; q++) acc[q] = 0.0;
+        const double *lp = L + (long)(k * 128) * ld + b * 128 + t;
+        for (int r = 0; r < 128; r++) {
+            const double l = lp[(long)r * ld];
+#pragma unroll
+            for (int q = 0; q < DENSE_MAX_RHS; q++)
+                if (q < nrhs) acc[q] += l * xk[q][r];
+        }
+#pragma unroll
+        for (int q = 0; q < DENSE_MAX_RHS; q++)
+            if (q < nrhs) Y[(long)q * n + b * 128 + t] -= acc[q];
+    }
+}
+
+// forward, step k: z_k = invL_kk y_k (block 0 stores it to Z) ; y_b -= L[b][k] z_k for every block b > k.
+// grid = nb - k, block = 128.  Y (work) blocks > k are updated; Y block k is only read, Z is a separate buffer.
+__global__ __launch_bounds__(128) void fwdsub_step_kernel(const double *L, long ld, const double *invd_k, double *Y,
+                                                          double *Z, int n, int k, int nrhs) {
+    __shared__ double yk[DENSE_MAX_RHS][128];
+    __shared__ double zk[DENSE_MAX_RHS][128];
+    __shared__ double tile[128 * DP];
+    const int t = threadIdx.x;
+    const int b = k + blockIdx.x;
+    for (int q = 0; q < nrhs; q++) yk[q][t] = Y[(long)q * n + k * 128 + t];
+    __syncthreads();
+    for (int q = 0; q < nrhs; q++) {
+        double s = 0.0;
+        for (int c = 0; c <= t; c++) s += invd_k[t * 128 + c] * yk[q][c];   // row t of invL (lower)
+        zk[q][t] = s;
+    }
+    if (b != k) {
+        const double *lp = L + (long)(b * 128) * ld + k * 128 + t;
+        for (int r = 0; r < 128; r++) tile[r * DP + t] = lp[(long)r * ld];   // coalesced rows
+    }
+    __syncthreads();
+    if (b == k) {
+        for (int q = 0; q < nrhs; q++) Z[(long)q * n + k * 128 + t] = zk[q][t];
+    } else {
+        for (int q = 0; q < nrhs; q++) {
+            double s = 0.0;
+            for (int c = 0; c < 128; c++) s += tile[t * DP + c] * zk[q][c];
+            Y[(long)q * n + b * 128 + t] -= s;
+        }
+    }
+}
+
+__global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
+    const int k = blockIdx.x;
+    for (int idx = threadIdx.x; idx < 128 * 128; idx += blockDim.x) {
+        const int r = idx >> 7, c = idx & 127;
+        W[(long)(k * 128 + r) * ld + k * 128 + c] = invd[(long)k * 16384 + idx];
+    }
+}
+
+// M[c][r] = M[r][c] for c < r, tile by tile through LDS
+__global__ __launch_bounds__(256) void symmetrize_kernel(double *M, long ld, int nt) {
+    __shared__ double tile[32][33];
+    // lower-triangle tile index
+    const int t = blockIdx.x;
+    int tr = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((long)(tr + 1) * (tr + 2) / 2 <= t) ++tr;
+    while ((long)tr * (tr + 1) / 2 > t) --tr;
+    const int tc = t - tr * (tr + 1) / 2;
+    (void)nt;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int y = ty; y < 32; y += 8) tile[y][tx] = M[(long)(tr * 32 + y) * ld + tc * 32 + tx];
+    __syncthreads();
+    for (int y = ty; y < 32; y += 8) {
+        const int r = tc * 32 + y, c = tr * 32 + tx;   // transposed position
+        if (c > r) M[(long)r * ld + c] = tile[tx][y];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse) {
+    stream = s;
+    n = n_padded;
+    ld = n_padded;
+    owns = true;
+    const size_t sq = (size_t)n * ld * sizeof(double);
+    HIPCHK(hipMalloc(&L, sq));
+    HIPCHK(hipMalloc(&invd, (size_t)(n / 128) * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&d_info, sizeof(int)));
+    if (with_inverse) {
+        HIPCHK(hipMalloc(&W, sq));
+        HIPCHK(hipMalloc(&Q, sq));
+        const size_t half = (size_t)(n / 2 + 128);
+        T_elems = half * half;
+        HIPCHK(hipMalloc(&T, T_elems * sizeof(double)));
+    }
+    return hipSuccess;
+}
+
+void DenseSolver::release() {
+    if (!owns) return;
+    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(T);
+    L = invd = W = Q = T = nullptr;
+    d_info = nullptr;
+    owns = false;
+}
+
+hipError_t DenseSolver::potrf() {
+    const int nb = n / 128;
+    HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
+    for (int k = 0; k < nb; k++) {
+        double *Akk = L + (long)(k * 128) * ld + k * 128;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, Akk, ld, invd + (long)k * 16384, d_info, k);
+        const int rows = n - (k + 1) * 128;
+        if (rows <= 0) break;
+        double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
+        GemmArgs g{};
+        // L21 = A21 * inv(L11)'   (in place: one column tile, every workgroup reads and writes only its own rows)
+        g.A = A21; g.lda = ld; g.B = invd + (long)k * 16384; g.ldb = 128; g.C = A21; g.ldc = ld;
+        g.M = rows; g.N = 128; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0; g.kmode = KMODE_FULL;
+        HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, g));
+        // A22 -= L21 * L21'  (lower tiles)
+        GemmArgs u{};
+        u.A = A21; u.lda = ld; u.B = A21; u.ldb = ld; u.C = L + (long)((k + 1) * 128) * ld + (k + 1) * 128; u.ldc = ld;
+        u.M = rows; u.N = rows; u.K = 128; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
+        HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, u));
+    }
+    return hipGetLastError();
+}
+
+hipError_t DenseSolver::forwardsolve(double *Ywork, double *Z, int nrhs) {
+    const int nb = n / 128;
+    for (int k = 0; k < nb; k++)
+        hipLaunchKernelGGL(fwdsub_step_kernel, dim3(nb - k), dim3(128), 0, stream, L, ld, invd + (long)k * 16384, Ywork,
+                           Z, n, k, nrhs);
+    return hipGetLastError();
+}
+
+hipError_t DenseSolver::backsolve(const double *Y, double *Ywork, double *X, int nrhs) {
+    const int nb = n / 128;
+    HIPCHK(hipMemcpyAsync(Ywork, Y, (size_t)nrhs * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    for (int k = nb - 1; k >= 0; k--)
+        hipLaunchKernelGGL(backsub_step_kernel, dim3(k + 1), dim3(128), 0, stream, L, ld, invd + (long)k * 16384, Ywork,
+                           X, n, k, nrhs);
+    return hipGetLastError();
+}
+
+// W[lo:hi, lo:hi] = inverse of L[lo:hi, lo:hi], recursively: off-diagonal block = -W22 * (L21 * W11)
+static hipError_t trtri_rec(DenseSolver &s, int lo, int hi) {
+    if (hi - lo <= 1) return hipSuccess;
+    const int mid = lo + (hi - lo) / 2;
+    HIPCHK(trtri_rec(s, lo, mid));
+    HIPCHK(trtri_rec(s, mid, hi));
+    const int M = (hi - mid) * 128, N = (mid - lo) * 128;
+    GemmArgs t{};
+    t.A = s.L + (long)(mid * 128) * s.ld + lo * 128; t.lda = s.ld;          // L21 (KC)
+    t.B = s.W + (long)(lo * 128) * s.ld + lo * 128; t.ldb = s.ld;           // W11 (k,j) row-major = XC, lower-triangular
+    t.C = s.T; t.ldc = N; t.M = M; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 0.0; t.kmode = KMODE_GE_COL;
+    HIPCHK(gemm_f64(s.stream, LAY_KC, LAY_XC, t));
+    GemmArgs w{};
+    w.A = s.W + (long)(mid * 128) * s.ld + mid * 128; w.lda = s.ld;         // W22 (KC), lower-triangular
+    w.B = s.T; w.ldb = N;                                                   // T (k,j) row-major = XC
+    w.C = s.W + (long)(mid * 128) * s.ld + lo * 128; w.ldc = s.ld;
+    w.M = M; w.N = N; w.K = M; w.alpha = -1.0; w.beta = 0.0; w.kmode = KMODE_LE_ROW;
+    return gemm_f64(s.stream, LAY_KC, LAY_XC, w);
+}
+
+hipError_t DenseSolver::trtri() {
+    const int nb = n / 128;
+    HIPCHK(hipMemsetAsync(W, 0, (size_t)n * ld * sizeof(double), stream));
+    hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(nb), dim3(256), 0, stream, invd, W, ld);
+    return trtri_rec(*this, 0, nb);
+}
+
+hipError_t DenseSolver::lauum() {
+    GemmArgs g{};
+    g.A = W; g.lda = ld; g.B = W; g.ldb = ld; g.C = Q; g.ldc = ld;
+    g.M = n; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.kmode = KMODE_GE_ROW;
+    return gemm_f64(stream, LAY_XC, LAY_XC, g);
+}
+
+hipError_t DenseSolver::symmetrize(double *M) {
+    const int nt = n / 32;
+    hipLaunchKernelGGL(symmetrize_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, M, ld, nt);
+    return hipGetLastError();
+}
+
+int DenseSolver::fetch_info() {
+    int h = -1;
+    if (hipMemcpyAsync(&h, d_info, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    return h;
+}
+
+}  // namespace jaicov

@@ -1,0 +1,1035 @@
+// C ABI of the normal-equation engine (include/jaicov_neq.h): host control + small glue kernels.  gfx950 only.
+// There is NO CPU fallback here: every entry point fails with JAICOV_ERR_NO_DEVICE / JAICOV_ERR_DEVICE when HIP is
+// unusable.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "../../include/jaicov_dense.h"
+#include "../../include/jaicov_neq.h"
+#include "ba_kernels.h"
+#include "dense.h"
+#include "gemm_f64.h"
+
+namespace jaicov {
+hipError_t launch_rows(hipStream_t, const DevProblem &, const double *, int, int, double *, double *);
+hipError_t launch_assemble_small(hipStream_t, const DevProblem &, const int32_t *, const int32_t *, int, const double *,
+                                 const double *, double, double *, double *);
+hipError_t launch_assemble_blocks(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
+                                  const double *, const double *, double *, double, double *, double *);
+hipError_t launch_shared_groups(hipStream_t, const DevProblem &, const double *, double, double *, double *,
+                                const double *, double *);
+hipError_t launch_omega(hipStream_t, const DevProblem &, const uint8_t *, int, int, const int32_t *, int, int,
+                        const double *, const double *, const double *, double, double *, double *);
+}  // namespace jaicov
+
+using namespace jaicov;
+
+static const double EPS53 = 1.1102230246251565e-16;   // Constant.EPS = 2^-53 (Constant.java:68-75)
+
+// ---------------------------------------------------------------------------------------------------------------
+// glue kernels
+// ---------------------------------------------------------------------------------------------------------------
+// BA:814-828: damping on unknown columns, then V = 1/sqrt(diag) where diag > EPS (V = 1 on the border, whose
+// diagonal is zero); padded rows get V = 1
+__global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int d, double lambda, double *V) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Upad) return;
+    double v = 1.0;
+    if (c >= d && c < U) {
+        double diag = N[(long)c * ld + c];
+        if (lambda > 0.0) {
+            diag += lambda * diag;
+            N[(long)c * ld + c] = diag;
+        }
+        v = diag > 1.1102230246251565e-16 ? 1.0 / sqrt(diag) : 1.0;
+    }
+    V[c] = v;
+}
+
+// M = V N V + Bh' Bh on the unknown block (lower part), identity on border and padding.  Bh: [d][Upad]
+__global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restrict__ N, double *__restrict__ M, long ld,
+                                                         int U, int Upad, int d, const double *__restrict__ V,
+                                                         const double *__restrict__ Bh) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j > i || j >= Upad) return;
+    double v;
+    if (i < d || i >= U || j < d) v = (i == j) ? 1.0 : 0.0;
+    else {
+        v = V[i] * N[(long)i * ld + j] * V[j];
+        for (int a = 0; a < d; a++) v += Bh[(long)a * Upad + i] * Bh[(long)a * Upad + j];
+    }
+    M[(long)i * ld + j] = v;
+}
+
+__global__ void scale_vec_kernel(const double *n, const double *V, double *out, int U, int Upad, int d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= Upad) return;
+    out[c] = (c >= d && c < U) ? V[c] * n[c] : 0.0;
+}
+
+// final cofactor: Qxx[i][j] = V_i V_j (Q[i][j] - sum_a G[a][i] H[a][j]) on the unknown block, border from F, E.
+// G, H, F: [d][Upad]; E: [d][d].  Lower part (j <= i) only.
+__global__ __launch_bounds__(256) void qfix_kernel(double *__restrict__ Q, long ld, int U, int Upad, int d,
+                                                   const double *__restrict__ V, const double *__restrict__ G,
+                                                   const double *__restrict__ H, const double *__restrict__ F,
+                                                   const double *__restrict__ E) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j > i || j >= Upad) return;
+    double v;
+    if (i >= U) v = 0.0;
+    else if (i < d) v = E[i * d + j];
+    else if (j < d) v = F[(long)j * Upad + i];
+    else {
+        v = Q[(long)i * ld + j];
+        for (int a = 0; a < d; a++) v -= G[(long)a * Upad + i] * H[(long)a * Upad + j];
+        v *= V[i] * V[j];
+    }
+    Q[(long)i * ld + j] = v;
+}
+
+// row-major lower square <-> packed ('U' column-major == row-major lower packed)
+__global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ M, long ld, int U, double *__restrict__ ap) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j > i || i >= U) return;
+    ap[(size_t)i * (i + 1) / 2 + j] = M[(long)i * ld + j];
+}
+__global__ __launch_bounds__(256) void unpack_kernel(const double *__restrict__ ap, long ld, int U, double *__restrict__ M) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j > i || i >= U) return;
+    M[(long)i * ld + j] = ap[(size_t)i * (i + 1) / 2 + j];
+}
+__global__ void gather_sub_kernel(const double *__restrict__ Q, long ld, const int32_t *idx, int k, double *out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= k * k) return;
+    const int a = t / k, b = t - a * k;
+    const int i = idx[a], j = idx[b];
+    out[t] = i >= j ? Q[(long)i * ld + j] : Q[(long)j * ld + i];
+}
+// dense dispersion (row-major m x m) -> padded lower square with identity padding
+__global__ void load_disp_kernel(const double *__restrict__ D, int m, double *__restrict__ L, long ld, int mp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= mp) return;
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < m && j < m) v = D[(long)i * m + j];
+    L[(long)i * ld + j] = v;
+}
+__global__ void store_inv_kernel(const double *__restrict__ Q, long ld, int m, double *__restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= m) return;
+    out[(long)i * m + j] = i >= j ? Q[(long)i * ld + j] : Q[(long)j * ld + i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct jaicov_engine {
+    std::string err = "";
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevProblem p{};
+    std::vector<void *> allocs;
+    // host copies
+    jaicov_engine_options opts{};
+    int U = 0, Upad = 0, d = 0, datum_flags = 0, n_slots = 0;
+    std::vector<int32_t> h_slot_col, h_point_col;
+    std::vector<uint8_t> h_point_datum;
+    std::vector<double> h_vals, h_V;
+    int n_points = 0;
+    // image range handled by this engine
+    int ip0 = 0, ip_count = 0;
+    // assembly tables
+    int n_seg = 0, n_blk_list = 0, max_m = 0, n_blk_ip = 0;
+    int32_t *d_seg_begin = nullptr, *d_seg_end = nullptr, *d_blk_list = nullptr, *d_blk_ip_list = nullptr;
+    uint8_t *d_in_block = nullptr;
+    // device state
+    double *d_vals = nullptr, *d_rowsA = nullptr, *d_rowsW = nullptr, *d_T = nullptr, *d_vbuf = nullptr;
+    double *d_N = nullptr, *d_n = nullptr;          // one allocation: N (Upad x Upad) followed by n (Upad)
+    double *d_packed = nullptr;                     // reduce buffer: packed N (U(U+1)/2) + n (U)
+    double *d_V = nullptr, *d_B = nullptr, *d_Y = nullptr, *d_Yw = nullptr, *d_X = nullptr, *d_dx = nullptr;
+    double *d_omega = nullptr, *d_G = nullptr, *d_H = nullptr, *d_F = nullptr, *d_E = nullptr;
+    int32_t *d_idx = nullptr;
+    DenseSolver solver;
+    bool solver_has_inverse = false;
+    enum { ST_NEW, ST_PARAMS, ST_ACCUMULATED, ST_BUILT, ST_SOLVED } state = ST_NEW;
+    bool have_Q = false, rows_valid = false;
+    double lambda_used = 0.0;
+    std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
+    double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[10];
+};
+
+#define FAIL(e, code, msg)                 \
+    do {                                   \
+        (e)->err = (msg);                  \
+        return (code);                     \
+    } while (0)
+#define HIPE(e, x)                                                                        \
+    do {                                                                                  \
+        hipError_t _err = (x);                                                            \
+        if (_err != hipSuccess) {                                                         \
+            (e)->err = std::string(#x) + ": " + hipGetErrorString(_err);                  \
+            return _err == hipErrorOutOfMemory ? JAICOV_ERR_OUT_OF_MEMORY : JAICOV_ERR_DEVICE; \
+        }                                                                                 \
+    } while (0)
+
+template <typename T>
+static int upload(jaicov_engine *e, const T *src, size_t count, const T **dst) {
+    *dst = nullptr;
+    if (count == 0) return JAICOV_OK;
+    void *ptr = nullptr;
+    HIPE(e, hipMalloc(&ptr, count * sizeof(T)));
+    e->allocs.push_back(ptr);
+    HIPE(e, hipMemcpy(ptr, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const T *)ptr;
+    return JAICOV_OK;
+}
+template <typename T>
+static int dalloc(jaicov_engine *e, size_t count, T **dst, bool zero = false) {
+    *dst = nullptr;
+    if (count == 0) count = 1;
+    void *ptr = nullptr;
+    HIPE(e, hipMalloc(&ptr, count * sizeof(T)));
+    e->allocs.push_back(ptr);
+    if (zero) HIPE(e, hipMemset(ptr, 0, count * sizeof(T)));
+    *dst = (T *)ptr;
+    return JAICOV_OK;
+}
+
+static int check_device(std::string &err) {
+    int count = 0;
+    hipError_t r = hipGetDeviceCount(&count);
+    if (r != hipSuccess || count <= 0) {
+        err = "no HIP device available (this engine has no CPU fallback)";
+        return JAICOV_ERR_NO_DEVICE;
+    }
+    return JAICOV_OK;
+}
+
+// inverse of a dense SPD dispersion on the device: out (m x m row-major, device) = D^-1
+static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_D, int m, double *d_out) {
+    const int mp = ds.n;
+    hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp);
+    HIPE(e, ds.potrf());
+    HIPE(e, ds.trtri());
+    HIPE(e, ds.lauum());
+    hipLaunchKernelGGL(store_inv_kernel, dim3((m + 255) / 256, m), dim3(256), 0, e->stream, ds.Q, ds.ld, m, d_out);
+    const int info = ds.fetch_info();
+    if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)");
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_abi_version(void) { return JAICOV_NEQ_ABI_VERSION; }
+
+extern "C" const char *jaicov_neq_last_error(const jaicov_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    if (e->stream) hipStreamSynchronize(e->stream);
+    e->solver.release();
+    for (void *ptr : e->allocs) hipFree(ptr);
+    for (auto &evt : e->ev)
+        if (evt) hipEventDestroy(evt);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jaicov_engine_options *opts) {
+    HIPE(e, hipSetDevice(e->device));
+    hipDeviceProp_t prop;
+    HIPE(e, hipGetDeviceProperties(&prop, e->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        FAIL(e, JAICOV_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    HIPE(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto &evt : e->ev) HIPE(e, hipEventCreate(&evt));
+
+    const int U = D->n_unknowns, d = D->rank_defect;
+    e->U = U; e->d = d; e->datum_flags = D->datum_flags;
+    e->Upad = ((U + 127) / 128) * 128;
+    if (e->Upad == 0) e->Upad = 128;
+    e->n_points = D->n_points;
+    e->n_slots = 3 * D->n_points + 3 * D->n_cameras + D->n_dist + 6 * D->n_images;
+    // ---- validate --------------------------------------------------------------------------------------------
+    if (__builtin_popcount((unsigned)D->datum_flags) != d || d < 0 || d > 7) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "datum_flags / rank_defect mismatch");
+    for (int c = 0; c < D->n_cameras; c++) {
+        const int jb = D->cam_dist_begin[c], je = D->cam_dist_begin[c + 1];
+        if (je - jb > JAICOV_MAX_DIST_PER_CAMERA) FAIL(e, JAICOV_ERR_UNSUPPORTED, "too many distortion coefficients for one camera");
+        for (int j = jb + 1; j < je; j++)
+            if (D->dist_kind[j] < D->dist_kind[j - 1]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "distortion coefficients must be in DistortionModel.Type order");
+    }
+    for (int i = 1; i < D->n_image_points; i++)
+        if (D->ip_image[i] < D->ip_image[i - 1]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "image points must be image-major");
+    e->h_slot_col.resize(e->n_slots);
+    {
+        int s = 0;
+        for (int i = 0; i < 3 * D->n_points; i++) e->h_slot_col[s++] = D->point_col[i];
+        for (int i = 0; i < 3 * D->n_cameras; i++) e->h_slot_col[s++] = D->io_col[i];
+        for (int i = 0; i < D->n_dist; i++) e->h_slot_col[s++] = D->dist_col[i];
+        for (int i = 0; i < 6 * D->n_images; i++) e->h_slot_col[s++] = D->eo_col[i];
+        std::vector<char> seen(U > 0 ? U : 1, 0);
+        for (int c : e->h_slot_col) {
+            if (c == JAICOV_COL_FIXED) continue;
+            if (c < d || c >= U || seen[c]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "columns must be a permutation of d..U-1");
+            seen[c] = 1;
+        }
+    }
+    e->h_point_col.assign(D->point_col, D->point_col + 3 * D->n_points);
+    e->h_point_datum.assign(D->point_datum, D->point_datum + D->n_points);
+
+    // ---- image range of this engine ----------------------------------------------------------------------------
+    int ib = 0, ie = D->n_images;
+    if (opts && opts->image_begin >= 0 && opts->image_end >= 0) { ib = opts->image_begin; ie = opts->image_end; }
+    if (ib < 0 || ie > D->n_images || ib > ie) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "bad image range");
+    {
+        const int32_t *b = std::lower_bound(D->ip_image, D->ip_image + D->n_image_points, ib);
+        const int32_t *en = std::lower_bound(D->ip_image, D->ip_image + D->n_image_points, ie);
+        e->ip0 = (int)(b - D->ip_image);
+        e->ip_count = (int)(en - b);
+    }
+    // ---- blocks / segments -------------------------------------------------------------------------------------
+    std::vector<uint8_t> in_block(D->n_image_points + 1, 0);
+    std::vector<int32_t> blk_list, blk_ip_list, seg_b, seg_e;
+    std::vector<int64_t> blk_w_off(D->n_image_blocks + 1, 0);
+    int64_t w_total = 0;
+    for (int g = 0; g < D->n_image_blocks; g++) {
+        const int b = D->blk_ip_begin[g], en = D->blk_ip_begin[g + 1];
+        if (en < b || b < 0 || en > D->n_image_points) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "image blocks must be ascending ranges");
+        for (int ip = b; ip < en; ip++) {
+            if (D->ip_image[ip] != D->ip_image[b]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "an image block must not span images");
+            in_block[ip] = 1;
+        }
+        blk_w_off[g] = w_total;
+        const bool mine = en > b && D->ip_image[b] >= ib && D->ip_image[b] < ie;
+        if (mine) {
+            const int64_t m = 2 * (int64_t)(en - b);
+            w_total += m * m;
+            blk_list.push_back(g);
+            for (int ip = b; ip < en; ip++) blk_ip_list.push_back(ip);
+            e->max_m = std::max(e->max_m, (int)m);
+        }
+    }
+    for (int ip = e->ip0; ip < e->ip0 + e->ip_count;) {
+        if (in_block[ip]) { ip++; continue; }
+        int en = ip;
+        while (en < e->ip0 + e->ip_count && !in_block[en] && D->ip_image[en] == D->ip_image[ip] && en - ip < SEG) en++;
+        seg_b.push_back(ip); seg_e.push_back(en);
+        ip = en;
+    }
+    e->n_seg = (int)seg_b.size();
+    e->n_blk_list = (int)blk_list.size();
+    e->n_blk_ip = (int)blk_ip_list.size();
+
+    // ---- upload structure --------------------------------------------------------------------------------------
+    DevProblem &p = e->p;
+    p.U = U; p.Upad = e->Upad; p.d = d; p.ld = e->Upad;
+    p.n_points = D->n_points; p.n_cameras = D->n_cameras; p.n_images = D->n_images; p.n_dist = D->n_dist;
+    p.n_ip = D->n_image_points; p.n_blocks = D->n_image_blocks; p.n_sb = D->n_scale_bars; p.n_dg = D->n_direct_groups;
+    p.n_dg_rows = D->n_direct_rows; p.n_slots = e->n_slots;
+    int rc;
+#define UP(field, src, cnt) if ((rc = upload(e, src, (size_t)(cnt), &p.field)) != JAICOV_OK) return rc
+    UP(point_col, D->point_col, 3 * D->n_points);
+    UP(io_col, D->io_col, 3 * D->n_cameras);
+    UP(cam_dist_begin, D->cam_dist_begin, D->n_cameras + 1);
+    UP(dist_kind, D->dist_kind, D->n_dist);
+    UP(dist_order, D->dist_order, D->n_dist);
+    UP(dist_col, D->dist_col, D->n_dist);
+    UP(image_camera, D->image_camera, D->n_images);
+    UP(eo_col, D->eo_col, 6 * D->n_images);
+    UP(cam_r0, D->cam_r0, D->n_cameras);
+    UP(ip_image, D->ip_image, D->n_image_points);
+    UP(ip_point, D->ip_point, D->n_image_points);
+    UP(ip_x, D->ip_x, D->n_image_points);
+    UP(ip_y, D->ip_y, D->n_image_points);
+    UP(ip_var_x, D->ip_var_x, D->n_image_points);
+    UP(ip_var_y, D->ip_var_y, D->n_image_points);
+    UP(ip_rho, D->ip_rho, D->n_image_points);
+    UP(blk_ip_begin, D->blk_ip_begin, D->n_image_blocks + 1);
+    UP(blk_w_offset, blk_w_off.data(), D->n_image_blocks);
+    UP(sb_a, D->sb_point_a, D->n_scale_bars);
+    UP(sb_b, D->sb_point_b, D->n_scale_bars);
+    UP(sb_len, D->sb_length, D->n_scale_bars);
+    UP(sb_var, D->sb_var, D->n_scale_bars);
+    UP(dg_row_begin, D->dg_row_begin, D->n_direct_groups + 1);
+    UP(dg_slot, D->dg_slot, D->n_direct_rows);
+    UP(dg_obs, D->dg_obs, D->n_direct_rows);
+    UP(dg_var, D->dg_var, D->n_direct_rows);
+    UP(slot_col, e->h_slot_col.data(), e->n_slots);
+#undef UP
+    const int32_t *tmp32; const uint8_t *tmp8;
+    if ((rc = upload(e, seg_b.data(), seg_b.size(), &tmp32))) return rc; e->d_seg_begin = (int32_t *)tmp32;
+    if ((rc = upload(e, seg_e.data(), seg_e.size(), &tmp32))) return rc; e->d_seg_end = (int32_t *)tmp32;
+    if ((rc = upload(e, blk_list.data(), blk_list.size(), &tmp32))) return rc; e->d_blk_list = (int32_t *)tmp32;
+    if ((rc = upload(e, blk_ip_list.data(), blk_ip_list.size(), &tmp32))) return rc; e->d_blk_ip_list = (int32_t *)tmp32;
+    if ((rc = upload(e, in_block.data(), in_block.size(), &tmp8))) return rc; e->d_in_block = (uint8_t *)tmp8;
+
+    // ---- dense dispersions -> D^-1 on the device (DOPG:82-86: dpptrf + dpptri once, cached) -----------------------
+    {
+        double *d_w = nullptr;
+        if ((rc = dalloc(e, (size_t)w_total, &d_w))) return rc;
+        p.blk_w = d_w;
+        std::vector<int64_t> dg_w_off(D->n_direct_groups + 1, -1);
+        int64_t dg_total = 0;
+        int max_dm = 0;
+        if (e->opts.apply_shared)
+            for (int g = 0; g < D->n_direct_groups; g++) {
+                const int m = D->dg_row_begin[g + 1] - D->dg_row_begin[g];
+                if (D->dg_disp_offset && D->dg_disp_offset[g] >= 0 && m > 0) {
+                    dg_w_off[g] = dg_total;
+                    dg_total += (int64_t)m * m;
+                    max_dm = std::max(max_dm, m);
+                }
+            }
+        double *d_dgw = nullptr;
+        if ((rc = dalloc(e, (size_t)dg_total, &d_dgw))) return rc;
+        p.dg_w = d_dgw;
+        if ((rc = upload(e, dg_w_off.data(), (size_t)D->n_direct_groups, &p.dg_w_offset))) return rc;
+        const int mmax = std::max(e->max_m, max_dm);
+        if (mmax > 0) {
+            DenseSolver ds;
+            const int mp = ((mmax + 127) / 128) * 128;
+            HIPE(e, ds.init(e->stream, mp, true));
+            double *d_tmp = nullptr;
+            hipError_t he = hipMalloc(&d_tmp, (size_t)mmax * mmax * sizeof(double));
+            if (he != hipSuccess) { ds.release(); HIPE(e, he); }
+            int status = JAICOV_OK;
+            for (size_t t = 0; t < blk_list.size() && status == JAICOV_OK; t++) {
+                const int g = blk_list[t];
+                const int m = 2 * (D->blk_ip_begin[g + 1] - D->blk_ip_begin[g]);
+                hipMemcpyAsync(d_tmp, D->blk_disp + D->blk_disp_offset[g], (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, e->stream);
+                status = invert_dispersion(e, ds, d_tmp, m, d_w + blk_w_off[g]);
+            }
+            for (int g = 0; g < D->n_direct_groups && status == JAICOV_OK; g++) {
+                if (dg_w_off[g] < 0) continue;
+                const int m = D->dg_row_begin[g + 1] - D->dg_row_begin[g];
+                hipMemcpyAsync(d_tmp, D->dg_disp + D->dg_disp_offset[g], (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, e->stream);
+                status = invert_dispersion(e, ds, d_tmp, m, d_dgw + dg_w_off[g]);
+            }
+            hipStreamSynchronize(e->stream);
+            hipFree(d_tmp);
+            ds.release();
+            if (status != JAICOV_OK) return status;
+        }
+    }
+
+    // ---- work buffers ------------------------------------------------------------------------------------------
+    const size_t sq = (size_t)e->Upad * e->Upad;
+    if ((rc = dalloc(e, (size_t)e->n_slots, &e->d_vals))) return rc;
+    if ((rc = dalloc(e, (size_t)2 * KROW * std::max(1, D->n_image_points), &e->d_rowsA, true))) return rc;
+    if ((rc = dalloc(e, (size_t)2 * std::max(1, D->n_image_points), &e->d_rowsW, true))) return rc;
+    if ((rc = dalloc(e, (size_t)2 * std::max(1, D->n_image_points) * KC_LD, &e->d_T))) return rc;
+    if ((rc = dalloc(e, (size_t)2 * std::max(1, D->n_image_points), &e->d_vbuf))) return rc;
+    if ((rc = dalloc(e, sq + e->Upad, &e->d_N))) return rc;
+    e->d_n = e->d_N + sq;
+    if ((rc = dalloc(e, (size_t)e->Upad, &e->d_V))) return rc;
+    if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_B, true))) return rc;
+    if ((rc = dalloc(e, (size_t)DENSE_MAX_RHS * e->Upad, &e->d_Y, true))) return rc;
+    if ((rc = dalloc(e, (size_t)DENSE_MAX_RHS * e->Upad, &e->d_Yw, true))) return rc;
+    if ((rc = dalloc(e, (size_t)DENSE_MAX_RHS * e->Upad, &e->d_X, true))) return rc;
+    if ((rc = dalloc(e, (size_t)e->Upad, &e->d_dx, true))) return rc;
+    if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_G, true))) return rc;
+    if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_H, true))) return rc;
+    if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_F, true))) return rc;
+    if ((rc = dalloc(e, (size_t)64, &e->d_E, true))) return rc;
+    if ((rc = dalloc(e, (size_t)1, &e->d_omega, true))) return rc;
+    HIPE(e, e->solver.init(e->stream, e->Upad, false));
+    e->h_vals.assign(e->n_slots, 0.0);
+    e->h_V.assign(e->Upad, 1.0);
+    e->hB.assign((size_t)8 * e->Upad, 0.0);
+    HIPE(e, hipStreamSynchronize(e->stream));
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_create(const jaicov_problem_desc *desc, const jaicov_engine_options *opts, jaicov_engine **out) {
+    if (!out) return JAICOV_ERR_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!desc || desc->struct_size != sizeof(jaicov_problem_desc)) return JAICOV_ERR_BAD_ARGUMENT;
+    std::string err;
+    int rc = check_device(err);
+    if (rc != JAICOV_OK) return rc;
+    jaicov_engine *e = new jaicov_engine();
+    for (auto &evt : e->ev) evt = nullptr;
+    if (opts) {
+        if (opts->struct_size != sizeof(jaicov_engine_options)) { delete e; return JAICOV_ERR_BAD_ARGUMENT; }
+        e->opts = *opts;
+        e->device = opts->device;
+    } else {
+        e->opts.image_begin = e->opts.image_end = -1;
+        e->opts.apply_shared = 1;
+    }
+    *out = e;     // returned even on failure so that the caller can read jaicov_neq_last_error(); destroy() frees it
+    return create_impl(e, desc, opts);
+}
+
+extern "C" size_t jaicov_neq_num_slots(const jaicov_engine *e) { return e ? (size_t)e->n_slots : 0; }
+extern "C" size_t jaicov_neq_packed_length(const jaicov_engine *e) { return e ? (size_t)e->U * (e->U + 1) / 2 : 0; }
+
+extern "C" int jaicov_neq_set_parameters(jaicov_engine *e, const double *slots, size_t n) {
+    if (!e || !slots || n != (size_t)e->n_slots) return JAICOV_ERR_BAD_ARGUMENT;
+    HIPE(e, hipSetDevice(e->device));
+    memcpy(e->h_vals.data(), slots, n * sizeof(double));
+    HIPE(e, hipMemcpyAsync(e->d_vals, e->h_vals.data(), n * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));
+    e->rows_valid = false;
+    if (e->state == jaicov_engine::ST_NEW) e->state = jaicov_engine::ST_PARAMS;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_get_parameters(jaicov_engine *e, double *slots, size_t n) {
+    if (!e || !slots || n != (size_t)e->n_slots) return JAICOV_ERR_BAD_ARGUMENT;
+    memcpy(slots, e->h_vals.data(), n * sizeof(double));
+    return JAICOV_OK;
+}
+
+static int ensure_rows(jaicov_engine *e) {
+    if (e->rows_valid) return JAICOV_OK;
+    HIPE(e, launch_rows(e->stream, e->p, e->d_vals, e->ip0, e->ip_count, e->d_rowsA, e->d_rowsW));
+    e->rows_valid = true;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
+    if (!(sigma2 > 0)) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "variance of unit weight must be positive (DOPG:68-69)");
+    HIPE(e, hipSetDevice(e->device));
+    const size_t sq = (size_t)e->Upad * e->Upad;
+    HIPE(e, hipEventRecord(e->ev[0], e->stream));
+    int rc = ensure_rows(e);
+    if (rc) return rc;
+    HIPE(e, hipEventRecord(e->ev[1], e->stream));
+    HIPE(e, hipMemsetAsync(e->d_N, 0, (sq + e->Upad) * sizeof(double), e->stream));
+    HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
+    HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
+                                   e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n));
+    if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, e->d_N, e->d_n, nullptr, nullptr));
+    HIPE(e, hipEventRecord(e->ev[2], e->stream));
+    e->state = jaicov_engine::ST_ACCUMULATED;
+    e->have_Q = false;
+    return JAICOV_OK;
+}
+
+// datum rows on the host (BA:493-635) from the host copy of the parameter values
+static int datum_rows_host(jaicov_engine *e) {
+    const int d = e->d, Upad = e->Upad;
+    std::fill(e->hB.begin(), e->hB.end(), 0.0);
+    if (d == 0) return JAICOV_OK;
+    double x0 = 0, y0 = 0, z0 = 0;
+    int count = 0;
+    for (int pt = 0; pt < e->n_points; pt++) {
+        const int32_t *c = &e->h_point_col[3 * pt];
+        if (!e->h_point_datum[pt] || c[0] < 0 || c[1] < 0 || c[2] < 0) continue;
+        x0 += e->h_vals[3 * pt]; y0 += e->h_vals[3 * pt + 1]; z0 += e->h_vals[3 * pt + 2];
+        count++;
+    }
+    if (count < 3) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "not enough object points to realise the frame datum (BA:515-516)");
+    x0 /= (double)count; y0 /= (double)count; z0 /= (double)count;
+    int row = 0;
+    const int f = e->datum_flags;
+    const int tx = (f & JAICOV_DATUM_TX) ? row++ : -1, ty = (f & JAICOV_DATUM_TY) ? row++ : -1, tz = (f & JAICOV_DATUM_TZ) ? row++ : -1;
+    const int rx = (f & JAICOV_DATUM_RX) ? row++ : -1, ry = (f & JAICOV_DATUM_RY) ? row++ : -1, rz = (f & JAICOV_DATUM_RZ) ? row++ : -1;
+    const int ms = (f & JAICOV_DATUM_SCALE) ? row++ : -1;
+    double norm[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto B = [&](int r, int c) -> double & { return e->hB[(size_t)r * Upad + c]; };
+    for (int pt = 0; pt < e->n_points; pt++) {
+        const int32_t *c = &e->h_point_col[3 * pt];
+        if (!e->h_point_datum[pt] || c[0] < 0 || c[1] < 0 || c[2] < 0) continue;
+        const double x = e->h_vals[3 * pt] - x0, y = e->h_vals[3 * pt + 1] - y0, z = e->h_vals[3 * pt + 2] - z0;
+        if (tx >= 0) { B(tx, c[0]) = 1.0; norm[tx] += 1.0; }
+        if (ty >= 0) { B(ty, c[1]) = 1.0; norm[ty] += 1.0; }
+        if (tz >= 0) { B(tz, c[2]) = 1.0; norm[tz] += 1.0; }
+        if (rx >= 0) { B(rx, c[1]) = z; B(rx, c[2]) = -y; norm[rx] += z * z + y * y; }
+        if (ry >= 0) { B(ry, c[0]) = -z; B(ry, c[2]) = x; norm[ry] += z * z + x * x; }
+        if (rz >= 0) { B(rz, c[0]) = y; B(rz, c[1]) = -x; norm[rz] += x * x + y * y; }
+        if (ms >= 0) { B(ms, c[0]) = x; B(ms, c[1]) = y; B(ms, c[2]) = z; norm[ms] += x * x + y * y + z * z; }
+    }
+    for (int r = 0; r < d; r++) {
+        const double s = sqrt(norm[r]);
+        for (int c = 0; c < e->U; c++)
+            if (e->hB[(size_t)r * Upad + c] != 0.0) e->hB[(size_t)r * Upad + c] = e->hB[(size_t)r * Upad + c] / s;
+    }
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambda, int simulation) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    (void)sigma2;
+    if (e->state != jaicov_engine::ST_ACCUMULATED) FAIL(e, JAICOV_ERR_BAD_STATE, "accumulate first");
+    HIPE(e, hipSetDevice(e->device));
+    int rc = datum_rows_host(e);
+    if (rc) return rc;
+    hipLaunchKernelGGL(damp_and_precond_kernel, dim3((e->Upad + 255) / 256), dim3(256), 0, e->stream, e->d_N, (long)e->Upad,
+                       e->U, e->Upad, e->d, lambda > 0 ? lambda : 0.0, e->d_V);
+    if (simulation) HIPE(e, hipMemsetAsync(e->d_n, 0, e->Upad * sizeof(double), e->stream));   // BA:830-831
+    HIPE(e, hipEventRecord(e->ev[3], e->stream));
+    e->lambda_used = lambda;
+    e->state = jaicov_engine::ST_BUILT;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_build(jaicov_engine *e, double sigma2, double lambda, int simulation) {
+    int rc = jaicov_neq_accumulate(e, sigma2);
+    if (rc) return rc;
+    return jaicov_neq_finalize(e, sigma2, lambda, simulation);
+}
+
+extern "C" int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count) {
+    if (!e || !device_ptr || !count) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state != jaicov_engine::ST_ACCUMULATED) FAIL(e, JAICOV_ERR_BAD_STATE, "accumulate first");
+    // full square (lower part meaningful) followed by n: contiguous, summed as-is by the collective
+    *device_ptr = e->d_N;
+    *count = (size_t)e->Upad * e->Upad + e->Upad;
+    return JAICOV_OK;
+}
+
+// small dense helpers on the host (d <= 7)
+static bool small_inverse(int d, const double *S, double *Sinv) {
+    double a[7][14];
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) { a[i][j] = S[i * d + j]; a[i][d + j] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < d; c++) {
+        int piv = c;
+        for (int r = c + 1; r < d; r++)
+            if (fabs(a[r][c]) > fabs(a[piv][c])) piv = r;
+        if (a[piv][c] == 0.0) return false;
+        if (piv != c)
+            for (int j = 0; j < 2 * d; j++) std::swap(a[c][j], a[piv][j]);
+        const double inv = 1.0 / a[c][c];
+        for (int j = 0; j < 2 * d; j++) a[c][j] *= inv;
+        for (int r = 0; r < d; r++) {
+            if (r == c) continue;
+            const double f = a[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 2 * d; j++) a[r][j] -= f * a[c][j];
+        }
+    }
+    for (int i = 0; i < d; i++)
+        for (int j = 0; j < d; j++) Sinv[i * d + j] = a[i][d + j];
+    return true;
+}
+
+extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
+    if (!e || !dx_out) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state != jaicov_engine::ST_BUILT) FAIL(e, JAICOV_ERR_BAD_STATE, "build first");
+    HIPE(e, hipSetDevice(e->device));
+    const int U = e->U, Upad = e->Upad, d = e->d, nrhs = d + 1;
+    const long ld = Upad;
+    if (invert && !e->solver_has_inverse) {
+        const size_t sq = (size_t)Upad * Upad * sizeof(double);
+        HIPE(e, hipMalloc(&e->solver.W, sq));
+        HIPE(e, hipMalloc(&e->solver.Q, sq));
+        const size_t half = (size_t)(Upad / 2 + 128);
+        e->solver.T_elems = half * half;
+        HIPE(e, hipMalloc(&e->solver.T, e->solver.T_elems * sizeof(double)));
+        e->solver_has_inverse = true;
+    }
+    // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
+    HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));
+    std::vector<double> Bh((size_t)8 * Upad, 0.0);
+    double R[7] = {1, 1, 1, 1, 1, 1, 1};
+    for (int a = 0; a < d; a++) {
+        double s = 0.0;
+        for (int c = d; c < U; c++) {
+            const double v = e->hB[(size_t)a * Upad + c] * e->h_V[c];
+            Bh[(size_t)a * Upad + c] = v;
+            s += v * v;
+        }
+        if (!(s > 0.0)) FAIL(e, JAICOV_ERR_SINGULAR, "empty datum condition row");
+        R[a] = 1.0 / sqrt(s);
+        for (int c = d; c < U; c++) Bh[(size_t)a * Upad + c] *= R[a];
+    }
+    if (d > 0) HIPE(e, hipMemcpyAsync(e->d_B, Bh.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPE(e, hipEventRecord(e->ev[4], e->stream));
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((Upad + 255) / 256, Upad), dim3(256), 0, e->stream, e->d_N, e->solver.L, ld, U,
+                       Upad, d, e->d_V, e->d_B);
+    // right-hand sides: row 0 = V n, rows 1..d = Bh
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((Upad + 255) / 256), dim3(256), 0, e->stream, e->d_n, e->d_V, e->d_Y, U, Upad, d);
+    if (d > 0) HIPE(e, hipMemcpyAsync(e->d_Y + Upad, e->d_B, (size_t)d * Upad * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPE(e, e->solver.potrf());
+    HIPE(e, hipEventRecord(e->ev[5], e->stream));
+    HIPE(e, hipMemcpyAsync(e->d_Yw, e->d_Y, (size_t)nrhs * Upad * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPE(e, e->solver.forwardsolve(e->d_Yw, e->d_X, nrhs));       // X <- L^-1 Y
+    HIPE(e, e->solver.backsolve(e->d_X, e->d_Yw, e->d_G, nrhs));  // G <- L^-T X   (row 0: y~, rows 1..d: G^)
+    HIPE(e, hipEventRecord(e->ev[6], e->stream));
+    std::vector<double> X((size_t)nrhs * Upad);
+    HIPE(e, hipMemcpyAsync(X.data(), e->d_G, X.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    const int info = e->solver.fetch_info();
+    if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "normal-equation matrix is singular / not positive definite at pivot " + std::to_string(info));
+    // ---- rank-d border algebra on the host ---------------------------------------------------------------------
+    double Sm[49], Sinv[49], kh[7];
+    std::vector<double> y(X.begin(), X.begin() + Upad);
+    if (d > 0) {
+        for (int a = 0; a < d; a++)
+            for (int b = 0; b < d; b++) {
+                double s = 0.0;
+                for (int c = d; c < U; c++) s += Bh[(size_t)a * Upad + c] * X[(size_t)(1 + b) * Upad + c];
+                Sm[a * d + b] = s;
+            }
+        if (!small_inverse(d, Sm, Sinv)) FAIL(e, JAICOV_ERR_SINGULAR, "datum conditions are linearly dependent");
+        double by[7];
+        for (int a = 0; a < d; a++) {
+            double s = 0.0;
+            for (int c = d; c < U; c++) s += Bh[(size_t)a * Upad + c] * X[c];
+            by[a] = s;
+        }
+        for (int a = 0; a < d; a++) {
+            double s = 0.0;
+            for (int b = 0; b < d; b++) s += Sinv[a * d + b] * by[b];
+            kh[a] = s;
+        }
+        for (int c = d; c < U; c++) {
+            double s = 0.0;
+            for (int a = 0; a < d; a++) s += X[(size_t)(1 + a) * Upad + c] * kh[a];
+            y[c] -= s;
+        }
+    }
+    for (int c = 0; c < U; c++) dx_out[c] = c < d ? R[c] * kh[c] : e->h_V[c] * y[c];
+    for (int c = 0; c < U; c++)
+        if (!std::isfinite(dx_out[c])) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite step");
+    if (invert) {
+        HIPE(e, e->solver.trtri());
+        HIPE(e, e->solver.lauum());
+        // H = Sinv G^ ; F = R (Sinv G^) V ; E = R (I - Sinv) R
+        std::vector<double> H((size_t)8 * Upad, 0.0), F((size_t)8 * Upad, 0.0);
+        double E[49];
+        for (int a = 0; a < d; a++) {
+            for (int c = d; c < U; c++) {
+                double s = 0.0;
+                for (int b = 0; b < d; b++) s += Sinv[a * d + b] * X[(size_t)(1 + b) * Upad + c];
+                H[(size_t)a * Upad + c] = s;
+                F[(size_t)a * Upad + c] = R[a] * s * e->h_V[c];
+            }
+            for (int b = 0; b < d; b++) E[a * d + b] = R[a] * ((a == b ? 1.0 : 0.0) - Sinv[a * d + b]) * R[b];
+        }
+        if (d > 0) {
+            HIPE(e, hipMemcpyAsync(e->d_H, H.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
+            HIPE(e, hipMemcpyAsync(e->d_F, F.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
+            HIPE(e, hipMemcpyAsync(e->d_E, E, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        }
+        hipLaunchKernelGGL(qfix_kernel, dim3((Upad + 255) / 256, Upad), dim3(256), 0, e->stream, e->solver.Q, ld, U, Upad, d,
+                           e->d_V, e->d_G + Upad, e->d_H, e->d_F, e->d_E);
+        HIPE(e, hipEventRecord(e->ev[7], e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        e->have_Q = true;
+    } else {
+        HIPE(e, hipEventRecord(e->ev[7], e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+    }
+    float ms;
+    hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timings[0] = ms;
+    hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timings[1] = ms;
+    hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timings[2] = ms;
+    hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); e->timings[3] = ms;
+    hipEventElapsedTime(&ms, e->ev[5], e->ev[6]); e->timings[4] = ms;
+    hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); e->timings[5] = ms;
+    hipEventElapsedTime(&ms, e->ev[0], e->ev[7]); e->timings[7] = ms;
+    e->state = jaicov_engine::ST_SOLVED;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_omega(jaicov_engine *e, double sigma2, const double *dx, double *omega) {
+    if (!e || !dx || !omega) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
+    HIPE(e, hipSetDevice(e->device));
+    int rc = ensure_rows(e);
+    if (rc) return rc;
+    hipEvent_t t0 = e->ev[8], t1 = e->ev[9];
+    HIPE(e, hipEventRecord(t0, e->stream));
+    HIPE(e, hipMemcpyAsync(e->d_dx, dx, (size_t)e->U * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPE(e, hipMemsetAsync(e->d_omega, 0, sizeof(double), e->stream));
+    HIPE(e, launch_omega(e->stream, e->p, e->d_in_block, e->ip0, e->ip_count, e->d_blk_list, e->n_blk_list, e->max_m,
+                         e->d_rowsA, e->d_rowsW, e->d_dx, sigma2, e->d_vbuf, e->d_omega));
+    if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, nullptr, nullptr, e->d_dx, e->d_omega));
+    HIPE(e, hipEventRecord(t1, e->stream));
+    HIPE(e, hipMemcpyAsync(omega, e->d_omega, sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));
+    float ms;
+    hipEventElapsedTime(&ms, t0, t1);
+    e->timings[6] = ms;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_update(jaicov_engine *e, const double *dx, double *max_abs_dx) {
+    if (!e || !dx) return JAICOV_ERR_BAD_ARGUMENT;
+    HIPE(e, hipSetDevice(e->device));
+    double mx = 0.0;
+    for (int s = 0; s < e->n_slots; s++) {
+        const int c = e->h_slot_col[s];
+        if (c >= 0) {
+            const double dv = dx[c];
+            mx = std::max(mx, fabs(dv));
+            e->h_vals[s] = e->h_vals[s] + dv;
+        }
+    }
+    if (max_abs_dx) *max_abs_dx = mx;
+    HIPE(e, hipMemcpyAsync(e->d_vals, e->h_vals.data(), (size_t)e->n_slots * sizeof(double), hipMemcpyHostToDevice, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));
+    e->rows_valid = false;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_get_normal(jaicov_engine *e, double *N_packed, size_t len, double *n, size_t Ulen) {
+    if (!e || !N_packed || !n) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state != jaicov_engine::ST_BUILT && e->state != jaicov_engine::ST_SOLVED && e->state != jaicov_engine::ST_ACCUMULATED)
+        FAIL(e, JAICOV_ERR_BAD_STATE, "build first");
+    const int U = e->U;
+    if (len != (size_t)U * (U + 1) / 2 || Ulen != (size_t)U) return JAICOV_ERR_BAD_ARGUMENT;
+    HIPE(e, hipSetDevice(e->device));
+    double *d_ap = nullptr;
+    HIPE(e, hipMalloc(&d_ap, std::max<size_t>(len, 1) * sizeof(double)));
+    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, U, d_ap);
+    hipError_t he = hipMemcpyAsync(N_packed, d_ap, len * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(n, e->d_n, U * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    hipFree(d_ap);
+    HIPE(e, he);
+    // the datum border lives on the host (rows 0..d-1): K[r][c] = B[r][c]  (BA:548-593), packed index r + c(c+1)/2
+    if (e->state != jaicov_engine::ST_ACCUMULATED)
+        for (int r = 0; r < e->d; r++)
+            for (int c = e->d; c < U; c++) N_packed[(size_t)r + (size_t)c * (c + 1) / 2] = e->hB[(size_t)r * e->Upad + c];
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_t len) {
+    if (!e || !Q_packed) return JAICOV_ERR_BAD_ARGUMENT;
+    if (!e->have_Q) FAIL(e, JAICOV_ERR_BAD_STATE, "no cofactor matrix: solve with invert != 0 first (MatrixInversion.NONE, BA:1177)");
+    const int U = e->U;
+    if (len != (size_t)U * (U + 1) / 2) return JAICOV_ERR_BAD_ARGUMENT;
+    HIPE(e, hipSetDevice(e->device));
+    double *d_ap = nullptr;
+    HIPE(e, hipMalloc(&d_ap, std::max<size_t>(len, 1) * sizeof(double)));
+    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, e->solver.Q, (long)e->Upad, U, d_ap);
+    hipError_t he = hipMemcpyAsync(Q_packed, d_ap, len * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    hipFree(d_ap);
+    HIPE(e, he);
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx, int32_t k, double *out) {
+    if (!e || !idx || !out || k <= 0) return JAICOV_ERR_BAD_ARGUMENT;
+    if (!e->have_Q) FAIL(e, JAICOV_ERR_BAD_STATE, "no cofactor matrix: solve with invert != 0 first");
+    for (int i = 0; i < k; i++)
+        if (idx[i] < 0 || idx[i] >= e->U) return JAICOV_ERR_BAD_ARGUMENT;
+    HIPE(e, hipSetDevice(e->device));
+    int32_t *d_idx = nullptr;
+    double *d_out = nullptr;
+    HIPE(e, hipMalloc(&d_idx, (size_t)k * sizeof(int32_t)));
+    hipError_t he = hipMalloc(&d_out, (size_t)k * k * sizeof(double));
+    if (he == hipSuccess) he = hipMemcpyAsync(d_idx, idx, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
+    if (he == hipSuccess) {
+        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, e->solver.Q, (long)e->Upad, d_idx, k, d_out);
+        he = hipMemcpyAsync(out, d_out, (size_t)k * k * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    }
+    if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+    hipFree(d_idx); hipFree(d_out);
+    HIPE(e, he);
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_get_rows(jaicov_engine *e, int32_t ip_begin, int32_t ip_count, double *w, double *A) {
+    if (!e || !w || !A || ip_begin < e->ip0 || ip_count < 0 || ip_begin + ip_count > e->ip0 + e->ip_count) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
+    HIPE(e, hipSetDevice(e->device));
+    int rc = ensure_rows(e);
+    if (rc) return rc;
+    const size_t S = (size_t)e->p.n_ip;
+    std::vector<double> hA((size_t)2 * KROW * S), hW(2 * S);
+    HIPE(e, hipMemcpyAsync(hA.data(), e->d_rowsA, hA.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPE(e, hipMemcpyAsync(hW.data(), e->d_rowsW, hW.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));
+    for (int i = 0; i < ip_count; i++) {
+        const size_t ip = (size_t)ip_begin + i;
+        w[2 * i] = hW[ip]; w[2 * i + 1] = hW[S + ip];
+        for (int r = 0; r < 2; r++)
+            for (int l = 0; l < KROW; l++) A[((size_t)2 * i + r) * KROW + l] = hA[(size_t)(2 * l + r) * S + ip];
+    }
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n) {
+    if (!e || !ms) return JAICOV_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < n && i < 8; i++) ms[i] = e->timings[i];
+    return JAICOV_OK;
+}
+
+// BA.estimateModel (BA:203-387) + updateModel (BA:389-442), FULL / NONE inversion modes
+extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_options *o, jaicov_estimate_result *res) {
+    if (!e || !o || !res || o->struct_size != sizeof(jaicov_estimate_options)) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
+    const double SQRT_EPS = sqrt(EPS53);
+    const int max_iter = o->max_iterations;
+    auto t0 = std::chrono::steady_clock::now();
+    bool deriveFirst = o->lambda0 > 0;
+    double adapted = 0.0;
+    const double damping = fabs(o->lambda0);
+    double maxAbsDx = 0.0, lastValid = 0.0, omega = 0.0;
+    int runs = max_iter - 1;
+    bool isEstimated = false, complete = false, isConverge = true;
+    if (max_iter == 0) { complete = isEstimated = true; adapted = 0; }
+    const double sigma2 = o->sigma2apriori > 0 ? o->sigma2apriori : 1.0;
+    std::vector<double> dx(e->U > 0 ? e->U : 1);
+    int state = 0, iter = 0, rc = JAICOV_OK;
+    do {
+        auto tp = std::chrono::steady_clock::now();
+        maxAbsDx = 0.0;
+        iter = max_iter - runs;
+        if (deriveFirst) { adapted = damping; deriveFirst = false; }
+        rc = jaicov_neq_build(e, sigma2, adapted, o->simulation);
+        if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
+        if (rc) { state = rc == JAICOV_ERR_BAD_ARGUMENT || rc > 0 ? -2 : -1; break; }
+        complete = isEstimated;
+        rc = jaicov_neq_solve(e, complete && o->invert, dx.data());
+        if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
+        if (rc) { state = (rc > 0 || rc == JAICOV_ERR_BAD_ARGUMENT) ? -2 : -1; break; }
+        bool rejected = false;
+        if (adapted > 0) {
+            double alpha = 0.25 * pow(adapted, -0.05);
+            alpha = std::min(alpha, 0.75);
+            for (auto &v : dx) v *= alpha;
+            double prevOmega = omega, curOmega = 0.0;
+            if ((rc = jaicov_neq_omega(e, sigma2, dx.data(), &curOmega))) { state = -1; break; }
+            prevOmega = prevOmega <= 0 ? 1.7976931348623157e308 : prevOmega;
+            const bool lmaConverge = prevOmega >= curOmega;
+            omega = curOmega;
+            if (lmaConverge) adapted *= 0.2;
+            else {
+                adapted *= 5.0;
+                if (adapted > 1.0 / SQRT_EPS) { adapted = 1.0 / SQRT_EPS; omega = 0.0; }
+            }
+            if (!lmaConverge) { maxAbsDx = lastValid; rejected = true; }
+        }
+        if (!rejected) {
+            if (complete) {
+                if (o->simulation) omega = 0.0;
+                else if ((rc = jaicov_neq_omega(e, sigma2, dx.data(), &omega))) { state = -1; break; }
+            }
+            if ((rc = jaicov_neq_update(e, dx.data(), &maxAbsDx))) { state = -1; break; }
+            lastValid = maxAbsDx;
+        }
+        res->seconds_last_pass = std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+        if (std::isinf(maxAbsDx) || std::isnan(maxAbsDx)) { state = -2; break; }
+        else if (maxAbsDx <= SQRT_EPS && runs > 0 && adapted == 0) isEstimated = true;
+        else if (runs-- <= 1) {
+            if (complete) isConverge = false;
+            isEstimated = true;
+        }
+        if (isEstimated || adapted <= SQRT_EPS || runs < max_iter * 0.5 + 1) adapted = 0.0;
+    } while (!complete);
+    if (state == 0) state = isConverge ? 1 : -4;
+    res->state = state;
+    res->iterations = iter;
+    res->omega = omega;
+    res->max_abs_dx = maxAbsDx;
+    res->final_lambda = adapted;
+    res->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return (state == 1 || state == -4 || state == -2) ? JAICOV_OK : rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// jaicov_dense.h: stand-alone dense SPD solve / inverse (MX.solve / MX.inv on UpperSPDPackMatrix, MX:239-264,304-324)
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, int32_t nrhs, int32_t invert, double *ms_out) {
+    if (n <= 0 || !ap || nrhs < 0 || nrhs > DENSE_MAX_RHS || (nrhs > 0 && !b)) return JAICOV_ERR_BAD_ARGUMENT;
+    std::string err;
+    int rc = check_device(err);
+    if (rc) return rc;
+    hipStream_t s;
+    if (hipStreamCreate(&s) != hipSuccess) return JAICOV_ERR_DEVICE;
+    const int np = ((n + 127) / 128) * 128;
+    DenseSolver ds;
+    int status = JAICOV_OK;
+    double *d_ap = nullptr, *d_Y = nullptr, *d_Yw = nullptr, *d_X = nullptr;
+    const size_t len = (size_t)n * (n + 1) / 2;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    do {
+        if (ds.init(s, np, invert != 0) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
+        if (hipMalloc(&d_ap, len * sizeof(double)) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
+        hipMalloc(&d_Y, (size_t)DENSE_MAX_RHS * np * sizeof(double));
+        hipMalloc(&d_Yw, (size_t)DENSE_MAX_RHS * np * sizeof(double));
+        hipMalloc(&d_X, (size_t)DENSE_MAX_RHS * np * sizeof(double));
+        hipMemcpyAsync(d_ap, ap, len * sizeof(double), hipMemcpyHostToDevice, s);
+        // identity padding, then unpack the lower triangle
+        hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np);
+        hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, d_ap, ds.ld, n, ds.L);
+        hipMemsetAsync(d_Yw, 0, (size_t)DENSE_MAX_RHS * np * sizeof(double), s);
+        for (int q = 0; q < nrhs; q++) hipMemcpyAsync(d_Yw + (size_t)q * np, b + (size_t)q * n, n * sizeof(double), hipMemcpyHostToDevice, s);
+        hipEventRecord(e0, s);
+        if (ds.potrf() != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
+        if (nrhs > 0) {
+            ds.forwardsolve(d_Yw, d_X, nrhs);
+            ds.backsolve(d_X, d_Yw, d_Y, nrhs);
+        }
+        if (invert) {
+            ds.trtri();
+            ds.lauum();
+        }
+        hipEventRecord(e1, s);
+        const int info = ds.fetch_info();
+        if (info != 0) { status = JAICOV_ERR_SINGULAR; break; }
+        for (int q = 0; q < nrhs; q++) hipMemcpyAsync(b + (size_t)q * n, d_Y + (size_t)q * np, n * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (invert) {
+            hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, ds.Q, ds.ld, n, d_ap);
+            hipMemcpyAsync(ap, d_ap, len * sizeof(double), hipMemcpyDeviceToHost, s);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) status = JAICOV_ERR_DEVICE;
+        if (ms_out) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_out = ms; }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(d_ap); hipFree(d_Y); hipFree(d_Yw); hipFree(d_X);
+    ds.release();
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipStreamDestroy(s);
+    return status;
+}
+
+// C (M x N row-major) = alpha * op(A) op(B) + beta * C on the device, host buffers in/out (kernel parity + timing)
+extern "C" int jaicov_dense_gemm(int32_t alay, int32_t blay, int32_t M, int32_t N, int32_t K, double alpha, const double *A,
+                                 int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
+                                 int32_t lower_only, int32_t kmode, int32_t repeats, double *ms_out) {
+    if (M % 128 || N % 128 || K % 16 || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return JAICOV_ERR_BAD_ARGUMENT;
+    std::string err;
+    int rc = check_device(err);
+    if (rc) return rc;
+    const size_t sa = (size_t)(alay == LAY_KC ? M : K) * lda, sb = (size_t)(blay == LAY_KC ? N : K) * ldb, sc = (size_t)M * ldc;
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    if (hipMalloc(&dA, sa * 8) != hipSuccess || hipMalloc(&dB, sb * 8) != hipSuccess || hipMalloc(&dC, sc * 8) != hipSuccess) {
+        hipFree(dA); hipFree(dB); hipFree(dC);
+        return JAICOV_ERR_OUT_OF_MEMORY;
+    }
+    hipMemcpy(dA, A, sa * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dB, B, sb * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dC, C, sc * 8, hipMemcpyHostToDevice);
+    GemmArgs g{};
+    g.A = dA; g.B = dB; g.C = dC; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.alpha = alpha; g.beta = beta; g.lower_only = lower_only; g.kmode = kmode;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipError_t he = gemm_f64(nullptr, alay, blay, g);
+    hipMemcpy(C, dC, sc * 8, hipMemcpyDeviceToHost);
+    if (repeats > 0) {
+        hipEventRecord(e0, nullptr);
+        for (int r = 0; r < repeats; r++) gemm_f64(nullptr, alay, blay, g);
+        hipEventRecord(e1, nullptr);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        if (ms_out) *ms_out = ms / repeats;
+    }
+    he = he == hipSuccess ? hipDeviceSynchronize() : he;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return he == hipSuccess ? JAICOV_OK : JAICOV_ERR_DEVICE;
+}

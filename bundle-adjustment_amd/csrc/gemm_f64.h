@@ -1,0 +1,200 @@
+// fp64 MFMA GEMM family for gfx950 (v_mfma_f64_16x16x4_f64), the workhorse of the factorisation, the inverse and the
+// dense J'WJ contraction.  Row-major C.  One workgroup = 4 waves (2x2), 128x128 output tile, each wave 64x64 =
+// 4x4 MFMA tiles (16 accumulator tiles x 4 f64 = 128 VGPRs), BK = 16 per LDS stage, register-staged double buffering.
+//
+// Operand layouts (what is contiguous in global memory):
+//   A: LAY_KC  A(i,k) = A[i*lda + k]        A: LAY_XC  A(i,k) = A[k*lda + i]   (i.e. the transpose is stored)
+//   B: LAY_KC  B(k,j) = B[j*ldb + k]        B: LAY_XC  B(k,j) = B[k*ldb + j]
+// so  C = A.B^T of two row-major matrices is (KC,KC); C = A.B row-major is (KC,XC); C = A^T.B is (XC,XC).
+//
+// LDS image of both operands is k-major: S[k][x], row stride 144 doubles (1152 B == 128 mod 256), which makes the
+// MFMA fragment reads (lanes 0-15 -> 16 consecutive x at k, lanes 16-31 -> same x at k+1, ...) hit all 64 banks once
+// per 32-lane group: conflict-free ds_read_b64 (MI355X_MICROARCH.md, LDS table).
+//
+// f64 MFMA lane maps (cdna_hip_programming.md 3): A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// C/D: col = l&15, row = (l>>4) + 4*reg.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace jaicov {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+typedef double d2_t __attribute__((ext_vector_type(2)));
+
+enum { LAY_KC = 0, LAY_XC = 1 };
+enum { KMODE_FULL = 0, KMODE_LE_ROW = 1, KMODE_GE_ROW = 2, KMODE_GE_COL = 3 };
+
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDS_LD = 144;
+
+struct GemmArgs {
+    const double *A, *B;
+    double *C;
+    long lda, ldb, ldc;
+    int M, N, K;         // multiples of 128 / 128 / 16
+    double alpha, beta;  // C = alpha*A*B + beta*C
+    int lower_only;      // square tile grid: skip tiles with tile_col > tile_row
+    int kmode;           // restrict the k range per tile (triangular operands), see KMODE_*
+    long strideA, strideB, strideC;  // batch strides (blockIdx.y)
+};
+
+template <int ALAY, int BLAY>
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+    __shared__ double smem[2 * 2 * GEMM_BK * GEMM_LDS_LD];  // [stage][operand][k][x]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    int tile_row, tile_col;
+    {
+        const int t = blockIdx.x;
+        if (g.lower_only) {
+            // t -> (row, col) over the lower triangle, row-major: t = row(row+1)/2 + col
+            int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while ((long)(r + 1) * (r + 2) / 2 <= t) ++r;
+            while ((long)r * (r + 1) / 2 > t) --r;
+            tile_row = r;
+            tile_col = t - r * (r + 1) / 2;
+        } else {
+            const int tn = g.N / GEMM_BN;
+            tile_row = t / tn;
+            tile_col = t - tile_row * tn;
+        }
+    }
+    const long m0 = (long)tile_row * GEMM_BM, n0 = (long)tile_col * GEMM_BN;
+    int kbeg = 0, kend = g.K;
+    if (g.kmode == KMODE_LE_ROW) kend = min(g.K, (tile_row + 1) * GEMM_BM);
+    else if (g.kmode == KMODE_GE_ROW) kbeg = min(g.K, tile_row * GEMM_BM);
+    else if (g.kmode == KMODE_GE_COL) kbeg = min(g.K, tile_col * GEMM_BN);
+
+    const double *A = g.A + (long)blockIdx.y * g.strideA;
+    const double *B = g.B + (long)blockIdx.y * g.strideB;
+    double *C = g.C + (long)blockIdx.y * g.strideC;
+
+    // ---- global -> register staging (8 doubles per operand per thread) -------------------------------------
+    const double *ap, *bp;
+    long astep, bstep;
+    int a_lds, b_lds;  // LDS element offset of this thread's first element
+    if (ALAY == LAY_KC) {
+        const int row = tid & 127, kh = tid >> 7;
+        ap = A + (m0 + row) * g.lda + kbeg + 8 * kh;
+        astep = GEMM_BK;
+        a_lds = (8 * kh) * GEMM_LDS_LD + row;
+    } else {
+        const int kr = tid >> 4, ms = tid & 15;
+        ap = A + (long)(kbeg + kr) * g.lda + m0 + 8 * ms;
+        astep = (long)GEMM_BK * g.lda;
+        a_lds = kr * GEMM_LDS_LD + 8 * ms;
+    }
+    if (BLAY == LAY_KC) {
+        const int row = tid & 127, kh = tid >> 7;
+        bp = B + (n0 + row) * g.ldb + kbeg + 8 * kh;
+        bstep = GEMM_BK;
+        b_lds = (8 * kh) * GEMM_LDS_LD + row;
+    } else {
+        const int kr = tid >> 4, ns = tid & 15;
+        bp = B + (long)(kbeg + kr) * g.ldb + n0 + 8 * ns;
+        bstep = (long)GEMM_BK * g.ldb;
+        b_lds = kr * GEMM_LDS_LD + 8 * ns;
+    }
+
+    d2_t ra[4], rb[4];
+    auto gload = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ra[j] = *reinterpret_cast<const d2_t *>(ap + 2 * j);
+            rb[j] = *reinterpret_cast<const d2_t *>(bp + 2 * j);
+        }
+        ap += astep;
+        bp += bstep;
+    };
+    auto lstore = [&](int stage) {
+        double *sa = smem + (stage * 2 + 0) * GEMM_BK * GEMM_LDS_LD + a_lds;
+        double *sb = smem + (stage * 2 + 1) * GEMM_BK * GEMM_LDS_LD + b_lds;
+        if (ALAY == LAY_KC) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sa[(2 * j) * GEMM_LDS_LD] = ra[j].x;
+                sa[(2 * j + 1) * GEMM_LDS_LD] = ra[j].y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<d2_t *>(sa + 2 * j) = ra[j];
+        }
+        if (BLAY == LAY_KC) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                sb[(2 * j) * GEMM_LDS_LD] = rb[j].x;
+                sb[(2 * j + 1) * GEMM_LDS_LD] = rb[j].y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) *reinterpret_cast<d2_t *>(sb + 2 * j) = rb[j];
+        }
+    };
+
+    d4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+
+    const int nk = (kend - kbeg) / GEMM_BK;
+    if (nk > 0) {
+        gload();
+        lstore(0);
+        __syncthreads();
+        const int fa = (lane >> 4) * GEMM_LDS_LD + 64 * wr + (lane & 15);
+        const int fb = (lane >> 4) * GEMM_LDS_LD + 64 * wc + (lane & 15);
+        for (int kt = 0; kt < nk; kt++) {
+            const int st = kt & 1;
+            if (kt + 1 < nk) gload();
+            const double *sa = smem + (st * 2 + 0) * GEMM_BK * GEMM_LDS_LD + fa;
+            const double *sb = smem + (st * 2 + 1) * GEMM_BK * GEMM_LDS_LD + fb;
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                double a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[i] = sa[(4 * ks) * GEMM_LDS_LD + 16 * i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = sb[(4 * ks) * GEMM_LDS_LD + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nk) lstore(st ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    const double alpha = g.alpha, beta = g.beta;
+    double *cbase = C + (m0 + 64 * wr + (lane >> 4)) * g.ldc + n0 + 64 * wc + (lane & 15);
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double *p = cbase + (long)(16 * i + 4 * r) * g.ldc + 16 * j;
+                double v = alpha * acc[i][j][r];
+                if (beta != 0.0) v += beta * *p;
+                *p = v;
+            }
+}
+
+inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1) {
+    if (g.M <= 0 || g.N <= 0) return hipSuccess;
+    const int tm = g.M / GEMM_BM, tn = g.N / GEMM_BN;
+    const int tiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
+    dim3 grid(tiles, batch), block(256);
+    if (alay == LAY_KC && blay == LAY_KC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC>), grid, block, 0, s, g);
+    else if (alay == LAY_KC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_XC>), grid, block, 0, s, g);
+    else if (alay == LAY_XC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_XC, LAY_XC>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_f64_kernel<LAY_XC, LAY_KC>), grid, block, 0, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace jaicov

@@ -1,0 +1,59 @@
+"""CPU: the C-ABI library loads and exports every symbol the headers declare (no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from bundle_adjustment_amd import engine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(jaicov_(?:neq|dense)_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(engine.LIB_PATH):
+        engine.build_library()
+    lib = C.CDLL(engine.LIB_PATH)
+    declared = _declared("jaicov_neq.h") + _declared("jaicov_dense.h")
+    assert len(declared) >= 23
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert sorted(declared) == sorted(engine.EXPORTS)
+    assert lib.jaicov_neq_abi_version() == 1
+
+
+def test_struct_layout_matches_header():
+    from bundle_adjustment_amd.problem import ProblemDesc
+    # 13 int32-sized scalars (52 bytes, padded to 56) + 30 pointers
+    assert C.sizeof(ProblemDesc) == 56 + 30 * 8
+    assert C.sizeof(engine.EngineOptions) == 7 * 4 + 8 * 4
+    assert C.sizeof(engine.EstimateOptions) == 32
+    assert C.sizeof(engine.EstimateResult) == 48
+
+
+def test_no_cpu_fallback_without_device():
+    """On a box without a GPU the engine must refuse to create (never silently compute on the CPU)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from bundle_adjustment_amd import scene
+    fp = scene.config("tiny")
+    with pytest.raises(engine.EngineError) as ei:
+        engine.Engine(fp)
+    assert ei.value.code == -6
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "bundle-adjustment_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for pat in (r"import\s+oracle", r"from\s+oracle", r"ba_oracle", r"oracle/"):
+                    assert not re.search(pat, txt), f"{f} references the oracle ({pat})"

@@ -1,0 +1,192 @@
+"""GPU parity: the HIP path through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star): indexing bit-exact; estimated coordinates and covariances within 1e-9 relative.
+Row-level and matrix-level checks are tighter (1e-11 .. 1e-12), see each test.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from bundle_adjustment_amd import engine, scene
+from bundle_adjustment_amd.problem import full_to_packed, packed_to_full
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("alay,blay,kmode,lower", [(0, 0, 0, False), (0, 0, 0, True), (0, 1, 3, False), (0, 1, 1, False),
+                                                    (1, 1, 2, True), (1, 0, 0, False)])
+def test_gemm_f64_family(alay, blay, kmode, lower):
+    rng = np.random.default_rng(5)
+    M, N, K = 256, 384 if not lower else 256, 256
+    if kmode in (1, 2):
+        K = M
+    if kmode == 3:
+        K = N
+    Aop = rng.normal(size=(M, K)); Bop = rng.normal(size=(K, N)); C0 = rng.normal(size=(M, N))
+    # triangular operands for the restricted-k modes (the kernel skips the zero part)
+    tr = np.arange(M)[:, None] // 128; tk = np.arange(K)[None, :] // 128
+    if kmode == 1:
+        Aop = np.where(tk <= tr, Aop, 0.0)
+    if kmode == 2:
+        Aop = np.where(tk >= tr, Aop, 0.0)
+    if kmode == 3:
+        Bop = np.where((np.arange(K)[:, None] // 128) >= (np.arange(N)[None, :] // 128), Bop, 0.0)
+    A = Aop if alay == 0 else np.ascontiguousarray(Aop.T)
+    B = np.ascontiguousarray(Bop.T) if blay == 0 else Bop
+    ref = 0.75 * Aop @ Bop - 0.5 * C0
+    got, _ = engine.dense_gemm(alay, blay, A, B, C0, M, N, K, alpha=0.75, beta=-0.5, lower_only=lower, kmode=kmode)
+    if lower:
+        mask = (np.arange(M)[:, None] // 128) >= (np.arange(N)[None, :] // 128)
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=0, atol=1e-11)
+        np.testing.assert_array_equal(got[~mask], C0[~mask])
+    else:
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("n", [5, 128, 300, 1000])
+def test_dense_spd_solve_and_inverse(n):
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, n + 20))
+    S = G @ G.T / n + np.eye(n)
+    b = rng.normal(size=(3, n))
+    x, ap, _ = engine.dense_spd_solve_packed(full_to_packed(S), b, invert=True)
+    ref = np.linalg.solve(S, b.T).T
+    np.testing.assert_allclose(x, ref, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(packed_to_full(ap, n), np.linalg.inv(S), rtol=1e-9, atol=1e-12)
+
+
+def test_dense_not_spd_reports_singular():
+    S = -np.eye(130)
+    with pytest.raises(engine.EngineError) as ei:
+        engine.dense_spd_solve_packed(full_to_packed(S), np.ones((1, 130)))
+    assert ei.value.code == 1
+
+
+@pytest.mark.parametrize("name", ["pinhole", "radial", "full", "tangential2"])
+def test_rows_match_golden_and_oracle(oracle_mod, name):
+    sets = helpers.load_golden_rows()
+    dist, cases = sets[name]["dist"], sets[name]["cases"]
+    fp = helpers.problem_from_cases(dist, cases)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    w, A = eng.get_rows(0, fp.n_image_points)
+    o = oracle_mod.Oracle(fp)
+    nd = len(dist)
+    for i, c in enumerate(cases):
+        wo, Ao, _, _ = o.rows(fp.values, i)
+        np.testing.assert_allclose(w[i], wo, rtol=0, atol=1e-13)
+        scale = np.abs(Ao[:, :12 + nd]).max(axis=1, keepdims=True)
+        assert (np.abs(A[i, :, :12 + nd] - Ao[:, :12 + nd]) / np.maximum(np.abs(Ao[:, :12 + nd]), 1e-6 * scale)).max() < 1e-11
+        for r, key in enumerate(("Ax", "Ay")):
+            ref = np.array(c[key])
+            err = np.abs(A[i, r, :12 + nd] - ref) / np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+            assert err.max() < 1e-10
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
+def test_normal_equations_match_oracle(oracle_mod, name):
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    for lam in (0.0, 0.5):
+        No, no, Vo = o.build(fp.values, s2, lam)
+        eng = engine.Engine(fp)
+        eng.set_parameters(fp.values)
+        eng.build(s2, lam)
+        N, n = eng.get_normal()
+        U = fp.n_unknowns
+        Nf, Nof = packed_to_full(N, U), packed_to_full(No, U)
+        dg = np.sqrt(np.abs(np.diag(Nof))); dg[dg == 0] = 1.0
+        assert (np.abs(Nf - Nof) / np.outer(dg, dg)).max() < 1e-11
+        np.testing.assert_allclose(n, no, rtol=0, atol=1e-11 * np.abs(no).max())
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
+@pytest.mark.parametrize("invert", [False, True])
+def test_solve_matches_oracle(oracle_mod, name, invert):
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, invert)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.build(s2, 0.0)
+    dx = eng.solve(invert)
+    d = fp.rank_defect
+    np.testing.assert_allclose(dx[d:], dxo[d:], rtol=0, atol=1e-9 * np.abs(dxo[d:]).max())
+    np.testing.assert_allclose(dx[:d], dxo[:d], rtol=0, atol=1e-6 * max(np.abs(dxo[:d]).max(), 1e-30) + 1e-12)
+    om_o = o.omega(fp.values, s2, dxo)
+    assert abs(eng.omega(s2, dxo) - om_o) <= 1e-10 * om_o
+    if invert:
+        U = fp.n_unknowns
+        Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
+        sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
+        assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
+        np.testing.assert_allclose(np.diag(Q)[d:], np.diag(Qref)[d:], rtol=1e-9)
+        assert np.abs(Q - Qref).max() <= 1e-8 * np.abs(Qref).max()
+        idx = np.array([d, d + 3, U - 1, d + 1], np.int32)
+        np.testing.assert_array_equal(eng.get_cofactor_sub(idx), Q[np.ix_(idx, idx)])
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
+def test_estimate_matches_oracle(oracle_mod, name):
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    vo, Qo, ro = o.estimate()
+    eng = engine.Engine(fp)
+    v, r = eng.estimate()
+    assert r.state == ro.state == 1
+    assert r.iterations == ro.iterations
+    scale = np.maximum(np.abs(vo), 1e-3)
+    assert (np.abs(v - vo) / scale).max() < 1e-9
+    assert abs(r.omega - ro.omega) <= 1e-9 * ro.omega
+    U, d = fp.n_unknowns, fp.rank_defect
+    Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
+    np.testing.assert_allclose(np.diag(Q)[d:], np.diag(Qref)[d:], rtol=1e-8)
+    eng.close()
+
+
+def test_estimate_lm_and_simulation(oracle_mod):
+    fp = scene.config("tiny")
+    o = oracle_mod.Oracle(fp)
+    vo, _, ro = o.estimate(lam0=1.0)
+    eng = engine.Engine(fp)
+    v, r = eng.estimate(lam0=1.0)
+    assert r.state == ro.state == 1 and r.iterations == ro.iterations
+    assert (np.abs(v - vo) / np.maximum(np.abs(vo), 1e-3)).max() < 1e-8
+    eng.close()
+
+
+def test_sharded_engines_sum_to_full(oracle_mod):
+    fp = scene.config("tiny_block")
+    s2 = fp.sigma2apriori
+    full = engine.Engine(fp); full.set_parameters(fp.values); full.build(s2); N, n = full.get_normal()
+    h = fp.n_images // 2
+    a = engine.Engine(fp, image_range=(0, h), apply_shared=True)
+    b = engine.Engine(fp, image_range=(h, fp.n_images), apply_shared=False)
+    for e_ in (a, b):
+        e_.set_parameters(fp.values); e_.accumulate(s2)
+    Na, na = a.get_normal(); Nb, nb = b.get_normal()
+    np.testing.assert_allclose(Na + Nb, N, rtol=1e-12, atol=1e-13 * np.abs(N).max())
+    np.testing.assert_allclose(na + nb, n, rtol=1e-12, atol=1e-13 * np.abs(n).max())
+    for e_ in (full, a, b):
+        e_.close()
+
+
+def test_medium_config2_against_oracle(oracle_mod):
+    """BASELINE config 2 (20 x 200, radial, diagonal W): full estimate vs oracle."""
+    fp = scene.config("cfg2")
+    o = oracle_mod.Oracle(fp)
+    vo, Qo, ro = o.estimate()
+    eng = engine.Engine(fp)
+    v, r = eng.estimate()
+    assert r.state == ro.state == 1 and r.iterations == ro.iterations
+    assert (np.abs(v - vo) / np.maximum(np.abs(vo), 1e-3)).max() < 1e-9
+    Q = eng.get_cofactor()
+    U = fp.n_unknowns
+    dq = np.diag(packed_to_full(Q, U)); dqo = np.diag(packed_to_full(Qo, U))
+    np.testing.assert_allclose(dq, dqo, rtol=1e-9)
+    eng.close()
