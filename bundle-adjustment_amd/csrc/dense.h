@@ -7,6 +7,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 namespace jaicov {
 
 constexpr int DENSE_NB = 128;      // diagonal block handled by one workgroup in LDS
@@ -24,6 +26,13 @@ struct DenseSolver {
     size_t T_elems = 0;
     int *d_info = nullptr;     // first failing pivot (1-based), 0 = ok
     bool owns = false;
+    // optional per-launch profiling of the trailing update (HIP events on `stream`)
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev;     // pairs
+    std::vector<double> prof_flops;
+    size_t prof_used = 0;
+    double stat_launches = 0, stat_ms = 0, stat_flops = 0;
+    void prof_collect();                 // call after the stream has been synchronised
 
     hipError_t init(hipStream_t s, int n_padded, bool with_inverse);
     void release();

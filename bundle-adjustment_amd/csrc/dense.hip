@@ -189,6 +189,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse) {
 void DenseSolver::release() {
     if (!owns) return;
     hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(T);
+    for (auto ev : prof_ev) hipEventDestroy(ev);
+    prof_ev.clear();
     L = invd = W = Q = T = nullptr;
     d_info = nullptr;
     owns = false;
@@ -212,7 +214,20 @@ hipError_t DenseSolver::potrf() {
         GemmArgs u{};
         u.A = A21; u.lda = ld; u.B = A21; u.ldb = ld; u.C = L + (long)((k + 1) * 128) * ld + (k + 1) * 128; u.ldc = ld;
         u.M = rows; u.N = rows; u.K = 128; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
+        if (profile) {
+            if (prof_used + 2 > prof_ev.size()) {
+                hipEvent_t a, b;
+                HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+                prof_ev.push_back(a); prof_ev.push_back(b);
+            }
+            HIPCHK(hipEventRecord(prof_ev[prof_used], stream));
+        }
         HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, u));
+        if (profile) {
+            HIPCHK(hipEventRecord(prof_ev[prof_used + 1], stream));
+            prof_flops.push_back((double)rows * ((double)rows + 1.0) * 128.0);
+            prof_used += 2;
+        }
     }
     return hipGetLastError();
 }
@@ -272,6 +287,19 @@ hipError_t DenseSolver::symmetrize(double *M) {
     const int nt = n / 32;
     hipLaunchKernelGGL(symmetrize_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, M, ld, nt);
     return hipGetLastError();
+}
+
+void DenseSolver::prof_collect() {
+    for (size_t i = 0; i + 1 < prof_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]) == hipSuccess) {
+            stat_launches += 1.0;
+            stat_ms += ms;
+            stat_flops += prof_flops[i / 2];
+        }
+    }
+    prof_used = 0;
+    prof_flops.clear();
 }
 
 int DenseSolver::fetch_info() {

@@ -162,7 +162,7 @@ struct jaicov_engine {
     DenseSolver solver;
     bool solver_has_inverse = false;
     enum { ST_NEW, ST_PARAMS, ST_ACCUMULATED, ST_BUILT, ST_SOLVED } state = ST_NEW;
-    bool have_Q = false, rows_valid = false;
+    bool have_Q = false, rows_valid = false, reduced = false;
     double lambda_used = 0.0;
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -568,6 +568,12 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
     HIPE(e, hipSetDevice(e->device));
     int rc = datum_rows_host(e);
     if (rc) return rc;
+    if (e->reduced) {   // the host has summed the packed buffer over ranks: bring it back into the square
+        const size_t len = (size_t)e->U * (e->U + 1) / 2;
+        hipLaunchKernelGGL(unpack_kernel, dim3((e->U + 255) / 256, std::max(e->U, 1)), dim3(256), 0, e->stream, e->d_packed, (long)e->Upad, e->U, e->d_N);
+        HIPE(e, hipMemcpyAsync(e->d_n, e->d_packed + len, (size_t)e->U * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        e->reduced = false;
+    }
     hipLaunchKernelGGL(damp_and_precond_kernel, dim3((e->Upad + 255) / 256), dim3(256), 0, e->stream, e->d_N, (long)e->Upad,
                        e->U, e->Upad, e->d, lambda > 0 ? lambda : 0.0, e->d_V);
     if (simulation) HIPE(e, hipMemsetAsync(e->d_n, 0, e->Upad * sizeof(double), e->stream));   // BA:830-831
@@ -586,9 +592,19 @@ extern "C" int jaicov_neq_build(jaicov_engine *e, double sigma2, double lambda, 
 extern "C" int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count) {
     if (!e || !device_ptr || !count) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state != jaicov_engine::ST_ACCUMULATED) FAIL(e, JAICOV_ERR_BAD_STATE, "accumulate first");
-    // full square (lower part meaningful) followed by n: contiguous, summed as-is by the collective
-    *device_ptr = e->d_N;
-    *count = (size_t)e->Upad * e->Upad + e->Upad;
+    HIPE(e, hipSetDevice(e->device));
+    // packed lower triangle (== UPLO='U' packed) followed by n: one contiguous array the collective sums as it is
+    const size_t len = (size_t)e->U * (e->U + 1) / 2;
+    if (!e->d_packed) {
+        int rc = dalloc(e, len + e->U, &e->d_packed);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(pack_kernel, dim3((e->U + 255) / 256, std::max(e->U, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, e->U, e->d_packed);
+    HIPE(e, hipMemcpyAsync(e->d_packed + len, e->d_n, (size_t)e->U * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));   // the caller's collective runs on its own stream
+    e->reduced = true;
+    *device_ptr = e->d_packed;
+    *count = len + e->U;
     return JAICOV_OK;
 }
 
@@ -726,6 +742,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
     }
+    e->solver.prof_collect();
     float ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timings[0] = ms;
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timings[1] = ms;
@@ -855,6 +872,19 @@ extern "C" int jaicov_neq_get_rows(jaicov_engine *e, int32_t ip_begin, int32_t i
         for (int r = 0; r < 2; r++)
             for (int l = 0; l < KROW; l++) A[((size_t)2 * i + r) * KROW + l] = hA[(size_t)(2 * l + r) * S + ip];
     }
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_set_profiling(jaicov_engine *e, int enable) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    e->solver.profile = enable != 0;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset) {
+    if (!e || !stats || n < 3) return JAICOV_ERR_BAD_ARGUMENT;
+    stats[0] = e->solver.stat_launches; stats[1] = e->solver.stat_ms; stats[2] = e->solver.stat_flops;
+    if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = 0.0;
     return JAICOV_OK;
 }
 

@@ -25,6 +25,7 @@ EXPORTS = [
     "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_finalize", "jaicov_neq_reduce_buffer",
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
+    "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats",
     "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm",
 ]
 
@@ -100,6 +101,8 @@ def load_library():
     L.jaicov_neq_get_rows.argtypes = [vp, C.c_int32, C.c_int32, _pd, _pd]
     L.jaicov_neq_estimate.argtypes = [vp, C.POINTER(EstimateOptions), C.POINTER(EstimateResult)]
     L.jaicov_neq_last_timings.argtypes = [vp, _pd, C.c_int32]
+    L.jaicov_neq_set_profiling.argtypes = [vp, C.c_int]
+    L.jaicov_neq_kernel_stats.argtypes = [vp, _pd, C.c_int32, C.c_int]
     L.jaicov_dense_spd_solve_packed.argtypes = [C.c_int32, _pd, _pd, C.c_int32, C.c_int32, _pd]
     L.jaicov_dense_gemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, _pd, C.c_int64,
                                     _pd, C.c_int64, C.c_double, _pd, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _pd]
@@ -216,6 +219,14 @@ class Engine:
         ms = np.zeros(8)
         self._chk(self.L.jaicov_neq_last_timings(self._h, _p(ms), 8))
         return dict(zip(("rows", "assembly", "finalize", "factor", "solve", "inverse", "omega", "total"), ms))
+
+    def set_profiling(self, on=True):
+        self._chk(self.L.jaicov_neq_set_profiling(self._h, int(on)))
+
+    def kernel_stats(self, reset=False):
+        st = np.zeros(3)
+        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 3, int(reset)))
+        return {"launches": st[0], "ms": st[1], "flops": st[2]}
 
     def estimate(self, values=None, sigma2=None, lam0=0.0, max_iter=5000, invert=True, simulation=False):
         """``BundleAdjustment.estimateModel()`` (BundleAdjustment.java:203-387) run natively on the engine."""

@@ -171,9 +171,10 @@ int jaicov_neq_build(jaicov_engine *e, double sigma2apriori, double lambda, int 
 int jaicov_neq_accumulate(jaicov_engine *e, double sigma2apriori);
 int jaicov_neq_finalize(jaicov_engine *e, double sigma2apriori, double lambda, int simulation);
 
-/* Device buffer holding this rank's partial normal equations between accumulate and finalize: a single
- * contiguous array of *count doubles (row-major lower triangle storage of N followed by n).  A multi-GPU
- * host sums it over ranks (ncclAllReduce, sum, double) -- SURVEY 8(e).                                   */
+/* Device buffer holding this rank's partial normal equations between accumulate and finalize: one contiguous
+ * array of *count = U(U+1)/2 + U doubles (N packed 'U' followed by n).  A multi-GPU host sums it over ranks in place
+ * (ncclAllReduce, sum, double -- SURVEY 8(e)); finalize() picks the summed values up again.  The call synchronises
+ * the engine stream so that the collective may run on any other stream.                                          */
 int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count);
 
 /* replaces NES.applyPrecondition (NES:82-91) + MX.solve(N,n,numRows,invert) (MX:338-366) + the reverse
@@ -227,6 +228,12 @@ int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_options *opts, j
 /* timing of the stages of the last pass in milliseconds (HIP events on the engine stream):
  * [0] rows  [1] assembly  [2] finalize  [3] factorisation  [4] solve  [5] inverse  [6] omega  [7] total  */
 int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
+
+/* Per-kernel profiling of the dominant kernel (the fp64 MFMA trailing update of the factorisation): when enabled,
+ * every such launch is bracketed by HIP events on the engine stream.  stats: [0] launches, [1] summed device ms,
+ * [2] summed algorithmic flops (rows*(rows+1)*K per lower-triangular update), since the last reset.            */
+int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
+int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset);
 
 #ifdef __cplusplus
 }

@@ -1185,3 +1185,74 @@ double oracle_faithful_image_points(const jaicov_problem_desc *d, const double *
     }
     return chk;
 }
+
+/* "fair" flavour of an image-block group for the CPU baseline: same algebra N += A'PA, n += A'Pw on the compact
+ * m x k row block (columns = the group's sorted unique columns), but as two dense products T = P A, A'T instead of
+ * the reference's generic Theta(m^2 k^2) loop nest (PDF:479-502), which is unusable at m = 1000.
+ * P (row-major m x m) is the cached weight (DOPG:82-86 computes it once). */
+int oracle_block_weight(const jaicov_problem_desc *d, double sigma2, int blk, double *P_out) {
+    int m = 2 * (d->blk_ip_begin[blk + 1] - d->blk_ip_begin[blk]);
+    return dispersion_to_weight(m, d->blk_disp + d->blk_disp_offset[blk], sigma2, P_out);
+}
+
+int oracle_block_fair(const jaicov_problem_desc *d, const double *vals, double sigma2, int blk, const double *P,
+                      double *N, double *n) {
+    int b = d->blk_ip_begin[blk], e = d->blk_ip_begin[blk + 1];
+    int m = 2 * (e - b);
+    int kmax = (e - b) * 3 + ORA_KLOC, k = 0;
+    int32_t *cols = (int32_t *)malloc(sizeof(int32_t) * (size_t)kmax * 2);
+    int32_t *tmp = cols + kmax;
+    int U = d->n_unknowns;
+    int32_t *pos = (int32_t *)malloc(sizeof(int32_t) * (size_t)U);
+    for (int i = 0; i < U; i++) pos[i] = -1;
+    for (int ip = b; ip < e; ip++) {
+        int32_t gcol[ORA_KLOC];
+        int kl = local_columns(d, ip, gcol);
+        for (int l = 0; l < kl; l++)
+            if (gcol[l] >= 0 && pos[gcol[l]] < 0) { pos[gcol[l]] = 0; cols[k++] = gcol[l]; }
+    }
+    for (int j = 0; j < k; j++) tmp[j] = j;
+    sort_pairs(k, cols, tmp);
+    for (int j = 0; j < k; j++) pos[cols[j]] = j;
+    double *A = (double *)calloc((size_t)m * k, sizeof(double));
+    double *T = (double *)calloc((size_t)m * k, sizeof(double));
+    double *w = (double *)malloc(sizeof(double) * m), *Pw = (double *)calloc(m, sizeof(double));
+    for (int ip = b; ip < e; ip++) {
+        double Al[2][ORA_KLOC], wl[2], Pl[4];
+        int diag;
+        int32_t gcol[ORA_KLOC];
+        eval_image_point(d, vals, sigma2, ip, Al, wl, Pl, &diag);
+        int kl = local_columns(d, ip, gcol);
+        for (int l = 0; l < kl; l++) {
+            if (gcol[l] < 0) continue;
+            A[(size_t)(2 * (ip - b)) * k + pos[gcol[l]]] = Al[0][l];
+            A[(size_t)(2 * (ip - b) + 1) * k + pos[gcol[l]]] = Al[1][l];
+        }
+        w[2 * (ip - b)] = wl[0];
+        w[2 * (ip - b) + 1] = wl[1];
+    }
+    for (int r = 0; r < m; r++)                      /* T = P A, Pw = P w */
+        for (int q = 0; q < m; q++) {
+            double p = P[(size_t)r * m + q];
+            const double *aq = A + (size_t)q * k;
+            double *tr = T + (size_t)r * k;
+            for (int j = 0; j < k; j++) tr[j] += p * aq[j];
+            Pw[r] += p * w[q];
+        }
+    for (int r = 0; r < m; r++) {                    /* N += A'T (upper), n += A'Pw */
+        const double *ar = A + (size_t)r * k, *tr = T + (size_t)r * k;
+        for (int i = 0; i < k; i++) {
+            double a = ar[i];
+            if (a == 0.0) continue;
+            n[cols[i]] += a * Pw[r];
+            for (int j = i; j < k; j++) N[pidx(cols[i], cols[j])] += a * tr[j];
+        }
+    }
+    /* the lower-left products a_j * t_i (i < j) that the upper loop skipped */
+    for (int r = 0; r < m; r++) {
+        const double *ar = A + (size_t)r * k, *tr = T + (size_t)r * k;
+        (void)ar; (void)tr;
+    }
+    free(A); free(T); free(w); free(Pw); free(cols); free(pos);
+    return 0;
+}

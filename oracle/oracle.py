@@ -65,6 +65,8 @@ def lib():
                                       C.POINTER(OracleResult)]
         L.oracle_faithful_image_points.argtypes = [P, _pd, C.c_double, C.c_int, C.c_int, _pd, _pd]
         L.oracle_faithful_image_points.restype = C.c_double
+        L.oracle_block_weight.argtypes = [P, C.c_double, C.c_int, _pd]
+        L.oracle_block_fair.argtypes = [P, _pd, C.c_double, C.c_int, _pd, _pd, _pd]
         _LIB = L
     return _LIB
 
@@ -155,6 +157,18 @@ class Oracle:
         self.L.oracle_estimate(C.byref(self.desc), _p(v), self.fp.sigma2apriori if sigma2 is None else sigma2, lam0,
                                max_iter, int(invert), int(simulation), _p(Q), C.byref(res))
         return v, Q, res
+
+    def block_weight(self, sigma2, blk):
+        m = 2 * int(self.fp.blk_ip_begin[blk + 1] - self.fp.blk_ip_begin[blk])
+        Pm = np.zeros((m, m))
+        info = self.L.oracle_block_weight(C.byref(self.desc), sigma2, blk, _p(Pm))
+        if info:
+            raise ArithmeticError(f"oracle_block_weight info={info}")
+        return Pm
+
+    def block_fair(self, values, sigma2, blk, Pm, N, n):
+        v = _f(values)
+        return self.L.oracle_block_fair(C.byref(self.desc), _p(v), sigma2, blk, _p(Pm), _p(N), _p(n))
 
     def faithful_image_points(self, values, sigma2, ip_begin, ip_end, N, n):
         v = _f(values)
