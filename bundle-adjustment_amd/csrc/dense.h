@@ -18,6 +18,7 @@ struct DenseSolver {
     hipStream_t stream = nullptr;
     int n = 0;                 // padded order, multiple of 128
     long ld = 0;
+    int nbo = 512;             // outer panel width of the factorisation (multiple of 128)
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse

@@ -15,59 +15,150 @@ namespace jaicov {
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------
-// Diagonal block: Cholesky of a 128x128 SPD block held in LDS by one workgroup, plus the inverse of its factor.
-// A (global, lower part) <- L ; inv_out (128x128 row-major, zeros above the diagonal) <- L^-1.
+// Diagonal block: Cholesky of a 128x128 SPD block held in LDS by one workgroup (4 waves), plus the inverse of its
+// factor.  A (global, lower part) <- L ; inv_out (128x128 row-major, zeros above the diagonal) <- L^-1.
+//
+// Blocked with 16-wide panels: the 16x16 diagonal block is factored AND inverted in the registers of wave 0
+// (lane i = row i, operands broadcast with v_readlane), the panel solve and the trailing update run as
+// v_mfma_f64_16x16x4 tile products straight out of LDS (row stride 129 doubles: conflict-free fragment reads).
+// The inverse is built diagonal by diagonal: W[I][J] = -Wdd[I] * sum_{K=J}^{I-1} L[I][K] W[K][J]; the accumulator
+// of the first product IS the B fragment of the second (C/D rows (l>>4)+4r == B rows 4ks+(l>>4)), so it never
+// leaves the registers.  Off-diagonal W tiles are parked transposed in the (unused) strict upper part of S.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int DP = 129;  // padded LDS row (conflict-free column walks)
+constexpr int DP = 129;   // padded LDS row
+constexpr int WDP = 17;   // padded row of the 16x16 diagonal-block inverses
+
+// broadcast from a wave-uniform lane: two v_readlane_b32 (scalar path) instead of ds_bpermute round trips
+__device__ __forceinline__ double bcast(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
 
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, double *inv_out, int *info, int blk) {
     __shared__ double S[128 * DP];
-    __shared__ double xd[128];
-    const int tid = threadIdx.x;
+    __shared__ double Wd[8 * 16 * WDP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     for (int idx = tid; idx < 128 * 128; idx += 256) {
         const int r = idx >> 7, c = idx & 127;
         S[r * DP + c] = (c <= r) ? A[(long)r * ld + c] : 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < 128; j++) {
-        if (tid == 0) {
-            double d = S[j * DP + j];
-            if (!(d > 0.0)) {   // not positive definite (also catches NaN): MatrixNotSPDException / info > 0
-                atomicCAS(info, 0, blk * 128 + j + 1);
-                d = 1.0;
+    for (int p = 0; p < 8; p++) {
+        const int c0 = 16 * p;
+        if (wave == 0) {
+            // ---- 16x16 Cholesky + inverse in registers: lane i (< 16) holds row i -------------------------
+            double a[16], x[16], rinv[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) a[k] = S[(c0 + l15) * DP + c0 + k];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                double d = bcast(a[j], j);
+                if (!(d > 0.0)) {   // not positive definite (also NaN): MatrixNotSPDException / info > 0
+                    if (lane == 0) atomicCAS(info, 0, blk * 128 + c0 + j + 1);
+                    d = 1.0;
+                }
+                const double ljj = sqrt(d);
+                const double rl = 1.0 / ljj;
+                rinv[j] = rl;
+                a[j] = (l15 == j) ? ljj : a[j] * rl;
+#pragma unroll
+                for (int k = j + 1; k < 16; k++) {
+                    const double lkj = bcast(a[j], k);
+                    a[k] -= a[j] * lkj;
+                }
             }
-            S[j * DP + j] = sqrt(d);
+            // X = L^-1: lane c holds column c
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double sacc = (l15 == i) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) sacc -= bcast(a[k], i) * x[k];
+                x[i] = sacc * rinv[i];
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k <= lane) S[(c0 + lane) * DP + c0 + k] = a[k];
+                    Wd[p * 16 * WDP + k * WDP + lane] = x[k];          // Wdd[row k][col lane]
+                }
+            }
         }
         __syncthreads();
-        const double ljj = S[j * DP + j];
-        for (int i = j + 1 + tid; i < 128; i += 256) S[i * DP + j] /= ljj;
+        // ---- panel solve: L21 = A21 * Wdd' for the row tiles below ------------------------------------------
+        for (int R = p + 1 + wave; R < 8; R += 4) {
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const double av = S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
+                const double bv = Wd[p * 16 * WDP + l15 * WDP + 4 * ks + l4];   // B[k][j] = Wdd[j][k]
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + c0 + l15] = acc[r];
+        }
         __syncthreads();
-        for (int i = j + 1 + (tid >> 4); i < 128; i += 16) {
-            const double lij = S[i * DP + j];
-            for (int k = j + 1 + (tid & 15); k <= i; k += 16) S[i * DP + k] -= lij * S[k * DP + j];
+        // ---- trailing update of the lower tiles (R,Q), p < Q <= R -----------------------------------------------
+        const int rem = 7 - p, nt = rem * (rem + 1) / 2;
+        for (int t = wave; t < nt; t += 4) {
+            int rr = 0;
+            while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+            const int R = p + 1 + rr, Q = p + 1 + (t - rr * (rr + 1) / 2);
+            d4_t acc;
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[r] = S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15];
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const double av = -S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
+                const double bv = S[(16 * Q + l15) * DP + c0 + 4 * ks + l4];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15] = acc[r];
         }
         __syncthreads();
     }
-    // write the factor back (lower part only)
+    // factor back to global (lower part)
     for (int idx = tid; idx < 128 * 128; idx += 256) {
         const int r = idx >> 7, c = idx & 127;
         if (c <= r) A[(long)r * ld + c] = S[r * DP + c];
     }
-    // X = L^-1, column j by thread j; X[i][j] (i > j) is parked at S[j][i] (strict upper part), X[j][j] in xd
-    if (tid < 128) {
-        const int j = tid;
-        const double xjj = 1.0 / S[j * DP + j];
-        xd[j] = xjj;
-        for (int i = j + 1; i < 128; i++) {
-            double s = S[i * DP + j] * xjj;
-            for (int k = j + 1; k < i; k++) s += S[i * DP + k] * S[j * DP + k];
-            S[j * DP + i] = -s / S[i * DP + i];
+    // ---- inverse, one block diagonal after the other ---------------------------------------------------------
+    for (int t = 1; t < 8; t++) {
+        for (int J = wave; J < 8 - t; J += 4) {
+            const int I = J + t;
+            d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {   // K = J: L[I][J] * Wdd[J]
+                const double av = S[(16 * I + l15) * DP + 16 * J + 4 * ks + l4];
+                const double bv = Wd[J * 16 * WDP + (4 * ks + l4) * WDP + l15];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            for (int K = J + 1; K < I; K++) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const double av = S[(16 * I + l15) * DP + 16 * K + 4 * ks + l4];
+                    const double bv = S[(16 * J + l15) * DP + 16 * K + 4 * ks + l4];   // W[K][J] parked transposed
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+            }
+            d4_t acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const double av = Wd[I * 16 * WDP + l15 * WDP + 4 * ks + l4];
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[ks], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(16 * J + l15) * DP + 16 * I + l4 + 4 * r] = -acc2[r];
         }
+        __syncthreads();
     }
-    __syncthreads();
     for (int idx = tid; idx < 128 * 128; idx += 256) {
         const int r = idx >> 7, c = idx & 127;
-        inv_out[idx] = (c < r) ? S[c * DP + r] : (c == r ? xd[r] : 0.0);
+        double v = 0.0;
+        if (c <= r) v = ((r >> 4) == (c >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + (c & 15)] : S[c * DP + r];
+        inv_out[idx] = v;
     }
 }
 
@@ -196,24 +287,44 @@ void DenseSolver::release() {
     owns = false;
 }
 
+// Two-level right-looking Cholesky.  Outer panels of `nbo` columns (trailing update with K = nbo: enough flops per
+// byte of C to be MFMA-bound), inside a panel a left-looking sweep over 128-column blocks:
+//   block column kk -= L[kk:n, k0:kk] L[kk:kk+128, k0:kk]'     (fp64 MFMA GEMM, K grows to nbo-128)
+//   diagonal block factor + inverse (one workgroup, LDS)        L21 = A21 inv(L11)'  (GEMM with the inverse)
 hipError_t DenseSolver::potrf() {
     const int nb = n / 128;
+    const int bo = nbo / 128 > 0 ? nbo / 128 : 1;
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
-    for (int k = 0; k < nb; k++) {
-        double *Akk = L + (long)(k * 128) * ld + k * 128;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, Akk, ld, invd + (long)k * 16384, d_info, k);
-        const int rows = n - (k + 1) * 128;
+    for (int K0 = 0; K0 < nb; K0 += bo) {
+        const int K1 = K0 + bo < nb ? K0 + bo : nb;
+        for (int k = K0; k < K1; k++) {
+            double *Akk = L + (long)(k * 128) * ld + k * 128;
+            const int rows_k = n - k * 128;
+            if (k > K0) {
+                GemmArgs c{};
+                c.A = L + (long)(k * 128) * ld + K0 * 128; c.lda = ld;      // L[k*128:n, K0*128 : k*128]
+                c.B = c.A; c.ldb = ld;                                       // first 128 rows of the same strip
+                c.C = Akk; c.ldc = ld; c.M = rows_k; c.N = 128; c.K = (k - K0) * 128;
+                c.alpha = -1.0; c.beta = 1.0; c.lower_only = 0; c.kmode = KMODE_FULL;
+                HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, c));
+            }
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, Akk, ld, invd + (long)k * 16384, d_info, k);
+            const int rows = rows_k - 128;
+            if (rows <= 0) break;
+            double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
+            GemmArgs g{};
+            // L21 = A21 * inv(L11)'   (in place: one column tile, every workgroup reads and writes only its own rows)
+            g.A = A21; g.lda = ld; g.B = invd + (long)k * 16384; g.ldb = 128; g.C = A21; g.ldc = ld;
+            g.M = rows; g.N = 128; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0; g.kmode = KMODE_FULL;
+            HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, g));
+        }
+        const int rows = n - K1 * 128;
         if (rows <= 0) break;
-        double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
-        GemmArgs g{};
-        // L21 = A21 * inv(L11)'   (in place: one column tile, every workgroup reads and writes only its own rows)
-        g.A = A21; g.lda = ld; g.B = invd + (long)k * 16384; g.ldb = 128; g.C = A21; g.ldc = ld;
-        g.M = rows; g.N = 128; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0; g.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, g));
-        // A22 -= L21 * L21'  (lower tiles)
+        // trailing update: A22 -= L21 * L21'  (lower tiles), K = width of the outer panel
         GemmArgs u{};
-        u.A = A21; u.lda = ld; u.B = A21; u.ldb = ld; u.C = L + (long)((k + 1) * 128) * ld + (k + 1) * 128; u.ldc = ld;
-        u.M = rows; u.N = rows; u.K = 128; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
+        u.A = L + (long)(K1 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
+        u.C = L + (long)(K1 * 128) * ld + K1 * 128; u.ldc = ld;
+        u.M = rows; u.N = rows; u.K = (K1 - K0) * 128; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
         if (profile) {
             if (prof_used + 2 > prof_ev.size()) {
                 hipEvent_t a, b;
@@ -225,7 +336,7 @@ hipError_t DenseSolver::potrf() {
         HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, u));
         if (profile) {
             HIPCHK(hipEventRecord(prof_ev[prof_used + 1], stream));
-            prof_flops.push_back((double)rows * ((double)rows + 1.0) * 128.0);
+            prof_flops.push_back((double)rows * ((double)rows + 1.0) * (double)u.K);
             prof_used += 2;
         }
     }

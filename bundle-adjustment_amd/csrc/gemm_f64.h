@@ -133,11 +133,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         }
     };
 
+    // accumulators start from (beta/alpha)*C, so the epilogue is a pure store (alpha*acc): the C tile is fetched while
+    // the first operand tiles are still in flight instead of as a dependent read-modify-write at the end.
+    const double alpha = g.alpha, beta = g.beta;
+    double *cbase = C + (m0 + 64 * wr + (lane >> 4)) * g.ldc + n0 + 64 * wc + (lane & 15);
     d4_t acc[4][4];
+    if (beta != 0.0) {
+        const double bs = beta / alpha;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[i][j][r] = bs * cbase[(long)(16 * i + 4 * r) * g.ldc + 16 * j];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    }
 
     const int nk = (kend - kbeg) / GEMM_BK;
     if (nk > 0) {
@@ -170,19 +184,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
-    const double alpha = g.alpha, beta = g.beta;
-    double *cbase = C + (m0 + 64 * wr + (lane >> 4)) * g.ldc + n0 + 64 * wc + (lane & 15);
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                double *p = cbase + (long)(16 * i + 4 * r) * g.ldc + 16 * j;
-                double v = alpha * acc[i][j][r];
-                if (beta != 0.0) v += beta * *p;
-                *p = v;
-            }
+            for (int r = 0; r < 4; r++) cbase[(long)(16 * i + 4 * r) * g.ldc + 16 * j] = alpha * acc[i][j][r];
 }
 
 inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1) {
