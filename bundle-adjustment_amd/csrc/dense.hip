@@ -163,71 +163,145 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// substitution steps (nrhs <= 8 vectors stored as rows of Y / X, length n)
+// substitution steps (nrhs <= 8 vectors stored as rows, length n).  One launch per 128-block; every launch streams
+// one block row / block column of L exactly once (128 KB per workgroup, coalesced), the workgroup that finishes the
+// NEXT diagonal block also applies its inverse, so the chain carries no redundant work.
 // ---------------------------------------------------------------------------------------------------------------
-// backward, step k: x_k = invL_kk' y_k ; y_b -= L[k][b]' x_k for every block b < k.   grid = k+1, block = 128
-__global__ __launch_bounds__(128) void backsub_step_kernel(const double *L, long ld, const double *invd_k, double *Y,
-                                                           double *X, int n, int k, int nrhs) {
-    __shared__ double yk[DENSE_MAX_RHS][128];
-    __shared__ double xk[DENSE_MAX_RHS][128];
-    const int t = threadIdx.x, b = blockIdx.x;
-    for (int q = 0; q < nrhs; q++) yk[q][t] = Y[(long)q * n + k * 128 + t];
-    __syncthreads();
-    for (int q = 0; q < nrhs; q++) {
-        double s = 0.0;
-        for (int r = t; r < 128; r++) s += invd_k[r * 128 + t] * yk[q][r];
-        xk[q][t] = s;
+// x = invL' y (TRANS) or invL y for one diagonal block; invd is 128x128 row-major lower.  256 threads.
+// v: [nrhs][128] in LDS (input), out: [nrhs][128] in LDS; tile: 128*DP scratch.
+template <bool TRANS>
+__device__ __forceinline__ void apply_diag_inverse(const double *__restrict__ invd, const double (*v)[128],
+                                                   double (*out)[128], double *tile, int nrhs) {
+    const int tid = threadIdx.x;
+    // coalesced load of the block into LDS
+#pragma unroll 4
+    for (int i = 0; i < 32; i++) {
+        const int r = (tid >> 6) + 4 * i, c = 2 * (tid & 63);
+        const d2_t x = *reinterpret_cast<const d2_t *>(invd + r * 128 + c);
+        tile[r * DP + c] = x.x;
+        tile[r * DP + c + 1] = x.y;
     }
     __syncthreads();
-    if (b == k) {
-        for (int q = 0; q < nrhs; q++) X[(long)q * n + k * 128 + t] = xk[q][t];
-    } else {
-        double acc[DENSE_MAX_RHS];
+    const int t = tid & 127, h = tid >> 7;
+    for (int q = h; q < nrhs; q += 2) {
+        double s = 0.0;
+        if (TRANS) {
+            for (int r = t; r < 128; r++) s += tile[r * DP + t] * v[q][r];
+        } else {
+            for (int c = 0; c <= t; c++) s += tile[t * DP + c] * v[q][c];
+        }
+        out[q][t] = s;
+    }
+    __syncthreads();
+}
+
+// backward, step k (k = nb-1 .. 1): y_b -= L[k][b]' x_k for b < k; the workgroup b = k-1 then sets x_{k-1}.
+// X block k must already hold x_k.  grid = k, block = 256.
+__global__ __launch_bounds__(256) void backsub_step_kernel(const double *__restrict__ L, long ld,
+                                                           const double *__restrict__ invd, double *Y, double *X, int n,
+                                                           int k, int nrhs) {
+    __shared__ double xk[DENSE_MAX_RHS][128];
+    __shared__ double part[DENSE_MAX_RHS][128];
+    __shared__ double tile[128 * DP];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int c = tid & 127, h = tid >> 7;
+    if (tid < 128)
+        for (int q = 0; q < nrhs; q++) xk[q][tid] = X[(long)q * n + k * 128 + tid];
+    __syncthreads();
+    double acc[DENSE_MAX_RHS];
 #pragma unroll
-        for (int q = 0; q < DENSE_MAX_RHS; q++) acc[q] = 0.0;
-        const double *lp = L + (long)(k * 128) * ld + b * 128 + t;
-        for (int r = 0; r < 128; r++) {
-            const double l = lp[(long)r * ld];
+    for (int q = 0; q < DENSE_MAX_RHS; q++) acc[q] = 0.0;
+    const double *lp = L + (long)(k * 128 + 64 * h) * ld + b * 128 + c;
+    for (int r0 = 0; r0 < 64; r0 += 16) {
+        double l[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) l[i] = lp[(long)(r0 + i) * ld];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
 #pragma unroll
             for (int q = 0; q < DENSE_MAX_RHS; q++)
-                if (q < nrhs) acc[q] += l * xk[q][r];
+                if (q < nrhs) acc[q] += l[i] * xk[q][64 * h + r0 + i];
+    }
+    if (h == 1)
+        for (int q = 0; q < nrhs; q++) part[q][c] = acc[q];
+    __syncthreads();
+    if (h == 0)
+        for (int q = 0; q < nrhs; q++) {
+            const double v = Y[(long)q * n + b * 128 + c] - (acc[q] + part[q][c]);
+            Y[(long)q * n + b * 128 + c] = v;
+            part[q][c] = v;
         }
-#pragma unroll
-        for (int q = 0; q < DENSE_MAX_RHS; q++)
-            if (q < nrhs) Y[(long)q * n + b * 128 + t] -= acc[q];
+    if (b == k - 1) {   // block-uniform
+        __syncthreads();
+        apply_diag_inverse<true>(invd + (long)(k - 1) * 16384, part, xk, tile, nrhs);
+        if (tid < 128)
+            for (int q = 0; q < nrhs; q++) X[(long)q * n + (k - 1) * 128 + tid] = xk[q][tid];
     }
 }
 
-// forward, step k: z_k = invL_kk y_k (block 0 stores it to Z) ; y_b -= L[b][k] z_k for every block b > k.
-// grid = nb - k, block = 128.  Y (work) blocks > k are updated; Y block k is only read, Z is a separate buffer.
-__global__ __launch_bounds__(128) void fwdsub_step_kernel(const double *L, long ld, const double *invd_k, double *Y,
-                                                          double *Z, int n, int k, int nrhs) {
-    __shared__ double yk[DENSE_MAX_RHS][128];
+// forward, step k (k = 0 .. nb-2): y_b -= L[b][k] z_k for b > k; the workgroup b = k+1 then sets z_{k+1}.
+// Z block k must already hold z_k.  grid = nb-1-k, block = 256.
+__global__ __launch_bounds__(256) void fwdsub_step_kernel(const double *__restrict__ L, long ld,
+                                                          const double *__restrict__ invd, double *Y, double *Z, int n,
+                                                          int k, int nrhs) {
     __shared__ double zk[DENSE_MAX_RHS][128];
+    __shared__ double part[DENSE_MAX_RHS][128];
     __shared__ double tile[128 * DP];
-    const int t = threadIdx.x;
-    const int b = k + blockIdx.x;
-    for (int q = 0; q < nrhs; q++) yk[q][t] = Y[(long)q * n + k * 128 + t];
-    __syncthreads();
-    for (int q = 0; q < nrhs; q++) {
-        double s = 0.0;
-        for (int c = 0; c <= t; c++) s += invd_k[t * 128 + c] * yk[q][c];   // row t of invL (lower)
-        zk[q][t] = s;
-    }
-    if (b != k) {
-        const double *lp = L + (long)(b * 128) * ld + k * 128 + t;
-        for (int r = 0; r < 128; r++) tile[r * DP + t] = lp[(long)r * ld];   // coalesced rows
-    }
-    __syncthreads();
-    if (b == k) {
-        for (int q = 0; q < nrhs; q++) Z[(long)q * n + k * 128 + t] = zk[q][t];
-    } else {
-        for (int q = 0; q < nrhs; q++) {
-            double s = 0.0;
-            for (int c = 0; c < 128; c++) s += tile[t * DP + c] * zk[q][c];
-            Y[(long)q * n + b * 128 + t] -= s;
+    const int tid = threadIdx.x, b = k + 1 + blockIdx.x;
+    if (tid < 128)
+        for (int q = 0; q < nrhs; q++) zk[q][tid] = Z[(long)q * n + k * 128 + tid];
+    {   // coalesced load of the tile L[b][k] into LDS: one row (1 KB) per wave instruction
+        const double *lp = L + (long)(b * 128) * ld + k * 128;
+#pragma unroll 8
+        for (int i = 0; i < 32; i++) {
+            const int r = (tid >> 6) + 4 * i, cc = 2 * (tid & 63);
+            const d2_t x = *reinterpret_cast<const d2_t *>(lp + (long)r * ld + cc);
+            tile[r * DP + cc] = x.x;
+            tile[r * DP + cc + 1] = x.y;
         }
     }
+    __syncthreads();
+    const int r = tid & 127, h = tid >> 7;
+    double acc[DENSE_MAX_RHS];
+#pragma unroll
+    for (int q = 0; q < DENSE_MAX_RHS; q++) acc[q] = 0.0;
+    for (int cc = 64 * h; cc < 64 * h + 64; cc++) {
+        const double l = tile[r * DP + cc];
+#pragma unroll
+        for (int q = 0; q < DENSE_MAX_RHS; q++)
+            if (q < nrhs) acc[q] += l * zk[q][cc];
+    }
+    if (h == 1)
+        for (int q = 0; q < nrhs; q++) part[q][r] = acc[q];
+    __syncthreads();
+    if (h == 0)
+        for (int q = 0; q < nrhs; q++) {
+            const double v = Y[(long)q * n + b * 128 + r] - (acc[q] + part[q][r]);
+            Y[(long)q * n + b * 128 + r] = v;
+            part[q][r] = v;
+        }
+    if (b == k + 1) {
+        __syncthreads();
+        apply_diag_inverse<false>(invd + (long)(k + 1) * 16384, part, zk, tile, nrhs);
+        if (tid < 128)
+            for (int q = 0; q < nrhs; q++) Z[(long)q * n + (k + 1) * 128 + tid] = zk[q][tid];
+    }
+}
+
+// first block of a chain: out_k = invL_kk(') y_k.  grid = 1, block = 256
+template <bool TRANS>
+__global__ __launch_bounds__(256) void diag_apply_kernel(const double *__restrict__ invd_k, const double *Y, double *X,
+                                                         int n, int k, int nrhs) {
+    __shared__ double v[DENSE_MAX_RHS][128];
+    __shared__ double o[DENSE_MAX_RHS][128];
+    __shared__ double tile[128 * DP];
+    const int tid = threadIdx.x;
+    if (tid < 128)
+        for (int q = 0; q < nrhs; q++) v[q][tid] = Y[(long)q * n + k * 128 + tid];
+    __syncthreads();
+    apply_diag_inverse<TRANS>(invd_k, v, o, tile, nrhs);
+    if (tid < 128)
+        for (int q = 0; q < nrhs; q++) X[(long)q * n + k * 128 + tid] = o[q][tid];
 }
 
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
@@ -345,18 +419,19 @@ hipError_t DenseSolver::potrf() {
 
 hipError_t DenseSolver::forwardsolve(double *Ywork, double *Z, int nrhs) {
     const int nb = n / 128;
-    for (int k = 0; k < nb; k++)
-        hipLaunchKernelGGL(fwdsub_step_kernel, dim3(nb - k), dim3(128), 0, stream, L, ld, invd + (long)k * 16384, Ywork,
-                           Z, n, k, nrhs);
+    hipLaunchKernelGGL(diag_apply_kernel<false>, dim3(1), dim3(256), 0, stream, invd, Ywork, Z, n, 0, nrhs);
+    for (int k = 0; k + 1 < nb; k++)
+        hipLaunchKernelGGL(fwdsub_step_kernel, dim3(nb - 1 - k), dim3(256), 0, stream, L, ld, invd, Ywork, Z, n, k, nrhs);
     return hipGetLastError();
 }
 
 hipError_t DenseSolver::backsolve(const double *Y, double *Ywork, double *X, int nrhs) {
     const int nb = n / 128;
     HIPCHK(hipMemcpyAsync(Ywork, Y, (size_t)nrhs * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    for (int k = nb - 1; k >= 0; k--)
-        hipLaunchKernelGGL(backsub_step_kernel, dim3(k + 1), dim3(128), 0, stream, L, ld, invd + (long)k * 16384, Ywork,
-                           X, n, k, nrhs);
+    hipLaunchKernelGGL(diag_apply_kernel<true>, dim3(1), dim3(256), 0, stream, invd + (long)(nb - 1) * 16384, Ywork, X, n,
+                       nb - 1, nrhs);
+    for (int k = nb - 1; k >= 1; k--)
+        hipLaunchKernelGGL(backsub_step_kernel, dim3(k), dim3(256), 0, stream, L, ld, invd, Ywork, X, n, k, nrhs);
     return hipGetLastError();
 }
 
