@@ -2,6 +2,7 @@
 // structure-aware: the shared camera/EO blocks of an image are reduced on chip (LDS) before they touch HBM, only the
 // point-indexed blocks go out as fp64 atomics.  N is row-major LOWER (== UPLO='U' column-major).  gfx950 only.
 #include "ba_kernels.h"
+#include "gemm_f64.h"
 
 namespace jaicov {
 
@@ -217,40 +218,97 @@ __global__ __launch_bounds__(256) void blk_pc_kernel(DevProblem p, const int32_t
 }
 
 // B4: point x point blocks: N[pt_p, pt_q] += A_p' Dinv[rows p, rows q] A_q * sigma2, q <= p within the block.
-// grid (ceil(mp/16), ceil(mp/16), n_blocks_in_list), block 16x16: x = q, y = p
-__global__ __launch_bounds__(256) void blk_pp_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+// One thread per (q, b): it owns COLUMN b of the 3x3 block and issues one atomic per row a, so the three lanes of a
+// point write 24 contiguous bytes of one row of N in a single wave instruction (one memory-side atomic request
+// instead of three).  grid (ceil(mp/64), mp, n_list), block 192 = 64 points q x 3 columns.
+__global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
                                                      const double *__restrict__ rowsA, double sigma2,
                                                      double *__restrict__ N) {
-    if (blockIdx.x > blockIdx.y) return;
     const int g = blk_list[blockIdx.z];
     const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb, m = 2 * mp;
-    const int q = blockIdx.x * 16 + threadIdx.x, pp = blockIdx.y * 16 + threadIdx.y;
-    if (pp >= mp || q > pp) return;
+    const int pp = blockIdx.y;
+    if (pp >= mp || (int)blockIdx.x * 64 > pp) return;
+    const int qq = threadIdx.x / 3, b = threadIdx.x - 3 * qq;
+    const int q = blockIdx.x * 64 + qq;
+    if (q > pp) return;
     const long S = p.n_ip;
     const double *P = p.blk_w + p.blk_w_offset[g];
-    const double P00 = P[(long)(2 * pp) * m + 2 * q], P01 = P[(long)(2 * pp) * m + 2 * q + 1];
-    const double P10 = P[(long)(2 * pp + 1) * m + 2 * q], P11 = P[(long)(2 * pp + 1) * m + 2 * q + 1];
+    const d2_t P0 = *reinterpret_cast<const d2_t *>(P + (long)(2 * pp) * m + 2 * q);
+    const d2_t P1 = *reinterpret_cast<const d2_t *>(P + (long)(2 * pp + 1) * m + 2 * q);
     const int ipp = ipb + pp, ipq = ipb + q;
     const int ptp = p.ip_point[ipp], ptq = p.ip_point[ipq];
-    double gq[2][3];   // Dinv_pq * A_q
-    int cq[3], cp[3];
-#pragma unroll
-    for (int b = 0; b < 3; b++) {
-        const double a0 = rowsA[(long)(2 * b) * S + ipq], a1 = rowsA[(long)(2 * b + 1) * S + ipq];
-        gq[0][b] = P00 * a0 + P01 * a1;
-        gq[1][b] = P10 * a0 + P11 * a1;
-        cq[b] = p.point_col[3 * ptq + b];
-        cp[b] = p.point_col[3 * ptp + b];
-    }
+    const int cq = p.point_col[3 * ptq + b];
+    if (cq < 0) return;
+    const double aq0 = rowsA[(long)(2 * b) * S + ipq], aq1 = rowsA[(long)(2 * b + 1) * S + ipq];
+    const double g0 = sigma2 * (P0.x * aq0 + P0.y * aq1), g1 = sigma2 * (P1.x * aq0 + P1.y * aq1);   // (Dinv_pq A_q)[:, b]
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        if (cp[a] < 0) continue;
-        const double a0 = rowsA[(long)(2 * a) * S + ipp], a1 = rowsA[(long)(2 * a + 1) * S + ipp];
+        if (pp == q && b > a) continue;          // diagonal pair: lower triangle of the symmetric 3x3 only
+        const int cp = p.point_col[3 * ptp + a];
+        if (cp < 0) continue;
+        nadd(N, p.ld, cp, cq, rowsA[(long)(2 * a) * S + ipp] * g0 + rowsA[(long)(2 * a + 1) * S + ipp] * g1);
+    }
+}
+
+// B4': point x point blocks without atomics.  One workgroup owns the rows of ONE object point p (3 rows of N) for a
+// chunk of PP_CW columns and keeps that strip in LDS; it walks the images that observe p, streams the two rows of the
+// image's Dinv that belong to p (coalesced) and adds A_p' Dinv_pq A_q for every point q of the image into the strip.
+// Inside one image all q are distinct points, so the LDS updates never collide; a barrier separates images.  The strip
+// is added to N (lower part, c <= r) once at the end: every entry of the point-point block has exactly one owner, the
+// sum order is fixed (images ascending) -> bitwise reproducible, no memory-side atomics.
+constexpr int PP_CW = 4992;
+__global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const int32_t *__restrict__ pt_ip_begin,
+                                                            const int32_t *__restrict__ pt_ip_list,
+                                                            const int32_t *__restrict__ blk_of_ip,
+                                                            const double *__restrict__ rowsA, double sigma2,
+                                                            double *__restrict__ N, int cmin) {
+    __shared__ double strip[3 * PP_CW];
+    const int pt = blockIdx.x, tid = threadIdx.x;
+    const int c0 = cmin + blockIdx.y * PP_CW;
+    const int cp0 = p.point_col[3 * pt], cp1 = p.point_col[3 * pt + 1], cp2 = p.point_col[3 * pt + 2];
+    const int rmax = max(cp0, max(cp1, cp2));
+    const int ob = pt_ip_begin[pt], oe = pt_ip_begin[pt + 1];
+    if (rmax < c0 || ob == oe) return;
+    for (int i = tid; i < 3 * PP_CW; i += 256) strip[i] = 0.0;
+    __syncthreads();
+    const long S = p.n_ip;
+    for (int o = ob; o < oe; o++) {
+        const int ip = pt_ip_list[o], g = blk_of_ip[ip];
+        const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb, m = 2 * mp, lp = ip - ipb;
+        const double *P = p.blk_w + p.blk_w_offset[g];
+        double ap0[3], ap1[3];
 #pragma unroll
-        for (int b = 0; b < 3; b++) {
-            if (cq[b] < 0) continue;
-            if (pp == q && b > a) continue;      // diagonal pair: lower triangle of the symmetric 3x3 only
-            nadd(N, p.ld, cp[a], cq[b], sigma2 * (a0 * gq[0][b] + a1 * gq[1][b]));
+        for (int a = 0; a < 3; a++) {
+            ap0[a] = sigma2 * rowsA[(long)(2 * a) * S + ip];
+            ap1[a] = sigma2 * rowsA[(long)(2 * a + 1) * S + ip];
+        }
+        for (int q = tid; q < mp; q += 256) {
+            const d2_t P0 = *reinterpret_cast<const d2_t *>(P + (long)(2 * lp) * m + 2 * q);
+            const d2_t P1 = *reinterpret_cast<const d2_t *>(P + (long)(2 * lp + 1) * m + 2 * q);
+            const int ptq = p.ip_point[ipb + q];
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int cq = p.point_col[3 * ptq + b];
+                if (cq < c0 || cq >= c0 + PP_CW) continue;
+                const double aq0 = rowsA[(long)(2 * b) * S + ipb + q], aq1 = rowsA[(long)(2 * b + 1) * S + ipb + q];
+                const double g0 = P0.x * aq0 + P0.y * aq1, g1 = P1.x * aq0 + P1.y * aq1;
+                if (cp0 >= cq) strip[cq - c0] += ap0[0] * g0 + ap1[0] * g1;
+                if (cp1 >= cq) strip[PP_CW + cq - c0] += ap0[1] * g0 + ap1[1] * g1;
+                if (cp2 >= cq) strip[2 * PP_CW + cq - c0] += ap0[2] * g0 + ap1[2] * g1;
+            }
+        }
+        __syncthreads();
+    }
+    const int cps[3] = {cp0, cp1, cp2};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const int r = cps[a];
+        if (r < 0) continue;
+        const int cend = min(PP_CW, r - c0 + 1);
+        double *nrow = N + (long)r * p.ld + c0;
+        for (int c = tid; c < cend; c += 256) {
+            const double v = strip[a * PP_CW + c];
+            if (v != 0.0) nrow[c] += v;
         }
     }
 }
@@ -421,15 +479,20 @@ hipError_t launch_assemble_small(hipStream_t s, const DevProblem &p, const int32
 
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
-                                  double *T, double sigma2, double *N, double *n) {
+                                  double *T, double sigma2, double *N, double *n, const PPGather &pp) {
     if (n_list <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + 127) / 128, n_list), dim3(128), 0, s, p, blk_list, rowsA, rowsW, T);
     hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, T, sigma2, N, n);
     const long tot = (long)n_ip_list * KC_LD;
     hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
                        ip_list, n_ip_list, rowsA, T, sigma2, N, n);
-    const int mp = max_m / 2, tq = (mp + 15) / 16;
-    hipLaunchKernelGGL(blk_pp_kernel, dim3(tq, tq, n_list), dim3(16, 16), 0, s, p, blk_list, rowsA, sigma2, N);
+    if (pp.pt_ip_begin) {
+        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(256), 0, s, p, pp.pt_ip_begin,
+                           pp.pt_ip_list, pp.blk_of_ip, rowsA, sigma2, N, pp.cmin);
+    } else {
+        const int mp = max_m / 2;
+        hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, p, blk_list, rowsA, sigma2, N);
+    }
     return hipGetLastError();
 }
 

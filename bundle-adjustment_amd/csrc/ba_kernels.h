@@ -36,6 +36,12 @@ struct DevProblem {
     const int32_t *slot_col;           // [n_slots]
 };
 
+// tables of the atomics-free point x point gather (assemble.hip, blk_pp_gather_kernel); null = use the atomic kernel
+struct PPGather {
+    const int32_t *pt_ip_begin = nullptr, *pt_ip_list = nullptr, *blk_of_ip = nullptr;
+    int cmin = 0, n_chunks = 0;
+};
+
 // ---- slot layout ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int slot_io(const DevProblem &p, int c) { return 3 * p.n_points + 3 * c; }
 __device__ __forceinline__ int slot_dist(const DevProblem &p, int j) { return 3 * p.n_points + 3 * p.n_cameras + j; }

@@ -22,7 +22,7 @@ hipError_t launch_rows(hipStream_t, const DevProblem &, const double *, int, int
 hipError_t launch_assemble_small(hipStream_t, const DevProblem &, const int32_t *, const int32_t *, int, const double *,
                                  const double *, double, double *, double *);
 hipError_t launch_assemble_blocks(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
-                                  const double *, const double *, double *, double, double *, double *);
+                                  const double *, const double *, double *, double, double *, double *, const PPGather &);
 hipError_t launch_shared_groups(hipStream_t, const DevProblem &, const double *, double, double *, double *,
                                 const double *, double *);
 hipError_t launch_omega(hipStream_t, const DevProblem &, const uint8_t *, int, int, const int32_t *, int, int,
@@ -152,6 +152,7 @@ struct jaicov_engine {
     int n_seg = 0, n_blk_list = 0, max_m = 0, n_blk_ip = 0;
     int32_t *d_seg_begin = nullptr, *d_seg_end = nullptr, *d_blk_list = nullptr, *d_blk_ip_list = nullptr;
     uint8_t *d_in_block = nullptr;
+    PPGather pp;
     // device state
     double *d_vals = nullptr, *d_rowsA = nullptr, *d_rowsW = nullptr, *d_T = nullptr, *d_vbuf = nullptr;
     double *d_N = nullptr, *d_n = nullptr;          // one allocation: N (Upad x Upad) followed by n (Upad)
@@ -372,6 +373,31 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
     if ((rc = upload(e, blk_list.data(), blk_list.size(), &tmp32))) return rc; e->d_blk_list = (int32_t *)tmp32;
     if ((rc = upload(e, blk_ip_list.data(), blk_ip_list.size(), &tmp32))) return rc; e->d_blk_ip_list = (int32_t *)tmp32;
     if ((rc = upload(e, in_block.data(), in_block.size(), &tmp8))) return rc; e->d_in_block = (uint8_t *)tmp8;
+    if (!blk_ip_list.empty() && !getenv("JAICOV_PP_ATOMIC")) {
+        // point -> block image points (CSR, image order) for the atomics-free point x point gather
+        std::vector<int32_t> cnt(D->n_points + 1, 0), blk_of_ip(D->n_image_points, -1);
+        for (size_t t = 0; t < blk_list.size(); t++)
+            for (int ip = D->blk_ip_begin[blk_list[t]]; ip < D->blk_ip_begin[blk_list[t] + 1]; ip++) blk_of_ip[ip] = blk_list[t];
+        for (int ip : blk_ip_list) cnt[D->ip_point[ip] + 1]++;
+        for (int i = 0; i < D->n_points; i++) cnt[i + 1] += cnt[i];
+        std::vector<int32_t> fill(cnt.begin(), cnt.end() - 1), list(blk_ip_list.size());
+        int cmin = 1 << 30, cmax = -1;
+        for (int ip : blk_ip_list) {
+            const int pt = D->ip_point[ip];
+            list[fill[pt]++] = ip;
+            for (int a = 0; a < 3; a++) {
+                const int c = D->point_col[3 * pt + a];
+                if (c >= 0) { cmin = std::min(cmin, c); cmax = std::max(cmax, c); }
+            }
+        }
+        if (cmax >= cmin) {
+            if ((rc = upload(e, cnt.data(), cnt.size(), &e->pp.pt_ip_begin))) return rc;
+            if ((rc = upload(e, list.data(), list.size(), &e->pp.pt_ip_list))) return rc;
+            if ((rc = upload(e, blk_of_ip.data(), blk_of_ip.size(), &e->pp.blk_of_ip))) return rc;
+            e->pp.cmin = cmin;
+            e->pp.n_chunks = (cmax - cmin + 4992) / 4992;
+        }
+    }
 
     // ---- dense dispersions -> D^-1 on the device (DOPG:82-86: dpptrf + dpptri once, cached) -----------------------
     {
@@ -511,7 +537,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     HIPE(e, hipMemsetAsync(e->d_N, 0, (sq + e->Upad) * sizeof(double), e->stream));
     HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
-                                   e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n));
+                                   e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, e->pp));
     if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, e->d_N, e->d_n, nullptr, nullptr));
     HIPE(e, hipEventRecord(e->ev[2], e->stream));
     e->state = jaicov_engine::ST_ACCUMULATED;
