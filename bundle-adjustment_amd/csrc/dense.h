@@ -11,6 +11,8 @@
 
 namespace jaicov {
 
+struct GemmArgs;
+
 constexpr int DENSE_NB = 128;      // diagonal block handled by one workgroup in LDS
 constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry at once
 
@@ -19,6 +21,9 @@ struct DenseSolver {
     int n = 0;                 // padded order, multiple of 128
     long ld = 0;
     int nbo = 512;             // outer panel width of the factorisation (multiple of 128)
+    bool lookahead = true;     // factor panel s+1 on `pstream` while the rest of trailing update s runs
+    hipStream_t pstream = nullptr;
+    std::vector<hipEvent_t> sync_ev;
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse
@@ -37,6 +42,8 @@ struct DenseSolver {
 
     hipError_t init(hipStream_t s, int n_padded, bool with_inverse);
     void release();
+    hipError_t panel(hipStream_t st, int K0, int K1);
+    hipError_t timed_gemm(hipStream_t st, const GemmArgs &u, double flops);
     hipError_t potrf();                                     // L <- chol(L); info via fetch_info()
     hipError_t backsolve(const double *Y, double *Ywork, double *X, int nrhs);   // solves L' X = Y, rows are vectors
     hipError_t forwardsolve(double *Ywork, double *Z, int nrhs);   // solves L Z = Y (rows are vectors; Ywork is clobbered)

@@ -35,6 +35,64 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {
     return __hiloint2double(hi, lo);
 }
 
+// 16x16 Cholesky + inverse of the diagonal block at (c0,c0) in the registers of ONE wave (lane i < 16 = row i).
+// The reciprocal square root replaces sqrt + divide on the 128-step critical path (v_rsq_f64 + Newton, ~1 ulp).
+__device__ __forceinline__ void chol16_inv(double *S, double *Wd_p, int c0, int lane, int *info, int blk) {
+    const int l15 = lane & 15;
+    double a[16], x[16], rinv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = S[(c0 + l15) * DP + c0 + k];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        double d = bcast(a[j], j);
+        if (!(d > 0.0)) {   // not positive definite (also NaN): MatrixNotSPDException / info > 0
+            if (lane == 0) atomicCAS(info, 0, blk * 128 + c0 + j + 1);
+            d = 1.0;
+        }
+        double rl = rsqrt(d);
+        rl = rl * (1.5 - 0.5 * d * rl * rl);         // one more Newton step: full fp64 accuracy
+        const double ljj = d * rl;
+        rinv[j] = rl;
+        a[j] = (l15 == j) ? ljj : a[j] * rl;
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) {
+            const double lkj = bcast(a[j], k);
+            a[k] -= a[j] * lkj;
+        }
+    }
+    // X = L^-1: lane c holds column c
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        double sacc = (l15 == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) sacc -= bcast(a[k], i) * x[k];
+        x[i] = sacc * rinv[i];
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (k <= lane) S[(c0 + lane) * DP + c0 + k] = a[k];
+            Wd_p[k * WDP + lane] = x[k];          // Wdd[row k][col lane]
+        }
+    }
+}
+
+// trailing-update tile (R,Q) of panel p:  S[R][Q] -= S[R][p] S[Q][p]'
+__device__ __forceinline__ void diag_update_tile(double *S, int R, int Q, int c0, int l15, int l4) {
+    d4_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const double av = -S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
+        const double bv = S[(16 * Q + l15) * DP + c0 + 4 * ks + l4];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15] = acc[r];
+}
+
+// inv_out must be zero above the diagonal on entry (the buffer is zero-filled once at allocation).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, double *inv_out, int *info, int blk) {
     __shared__ double S[128 * DP];
     __shared__ double Wd[8 * 16 * WDP];
@@ -45,47 +103,10 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
         S[r * DP + c] = (c <= r) ? A[(long)r * ld + c] : 0.0;
     }
     __syncthreads();
+    if (wave == 0) chol16_inv(S, Wd, 0, lane, info, blk);
+    __syncthreads();
     for (int p = 0; p < 8; p++) {
         const int c0 = 16 * p;
-        if (wave == 0) {
-            // ---- 16x16 Cholesky + inverse in registers: lane i (< 16) holds row i -------------------------
-            double a[16], x[16], rinv[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) a[k] = S[(c0 + l15) * DP + c0 + k];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                double d = bcast(a[j], j);
-                if (!(d > 0.0)) {   // not positive definite (also NaN): MatrixNotSPDException / info > 0
-                    if (lane == 0) atomicCAS(info, 0, blk * 128 + c0 + j + 1);
-                    d = 1.0;
-                }
-                const double ljj = sqrt(d);
-                const double rl = 1.0 / ljj;
-                rinv[j] = rl;
-                a[j] = (l15 == j) ? ljj : a[j] * rl;
-#pragma unroll
-                for (int k = j + 1; k < 16; k++) {
-                    const double lkj = bcast(a[j], k);
-                    a[k] -= a[j] * lkj;
-                }
-            }
-            // X = L^-1: lane c holds column c
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double sacc = (l15 == i) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; k++) sacc -= bcast(a[k], i) * x[k];
-                x[i] = sacc * rinv[i];
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    if (k <= lane) S[(c0 + lane) * DP + c0 + k] = a[k];
-                    Wd[p * 16 * WDP + k * WDP + lane] = x[k];          // Wdd[row k][col lane]
-                }
-            }
-        }
-        __syncthreads();
         // ---- panel solve: L21 = A21 * Wdd' for the row tiles below ------------------------------------------
         for (int R = p + 1 + wave; R < 8; R += 4) {
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -99,23 +120,20 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
             for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + c0 + l15] = acc[r];
         }
         __syncthreads();
-        // ---- trailing update of the lower tiles (R,Q), p < Q <= R -----------------------------------------------
-        const int rem = 7 - p, nt = rem * (rem + 1) / 2;
-        for (int t = wave; t < nt; t += 4) {
-            int rr = 0;
-            while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
-            const int R = p + 1 + rr, Q = p + 1 + (t - rr * (rr + 1) / 2);
-            d4_t acc;
-#pragma unroll
-            for (int r = 0; r < 4; r++) acc[r] = S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15];
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const double av = -S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
-                const double bv = S[(16 * Q + l15) * DP + c0 + 4 * ks + l4];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        if (p == 7) break;
+        // ---- phase A: block column p+1 of the trailing update (the next diagonal block and its panel) ----------
+        for (int R = p + 1 + wave; R < 8; R += 4) diag_update_tile(S, R, p + 1, c0, l15, l4);
+        __syncthreads();
+        // ---- phase B: wave 0 factors the next diagonal block while waves 1-3 finish the trailing update ----
+        if (wave == 0) {
+            chol16_inv(S, Wd + (p + 1) * 16 * WDP, 16 * (p + 1), lane, info, blk);
+        } else {
+            const int rem = 6 - p, nt = rem * (rem + 1) / 2;     // tiles (R,Q), p+2 <= Q <= R <= 7
+            for (int t = wave - 1; t < nt; t += 3) {
+                int rr = 0;
+                while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
+                diag_update_tile(S, p + 2 + rr, p + 2 + (t - rr * (rr + 1) / 2), c0, l15, l4);
             }
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15] = acc[r];
         }
         __syncthreads();
     }
@@ -156,9 +174,8 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
     }
     for (int idx = tid; idx < 128 * 128; idx += 256) {
         const int r = idx >> 7, c = idx & 127;
-        double v = 0.0;
-        if (c <= r) v = ((r >> 4) == (c >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + (c & 15)] : S[c * DP + r];
-        inv_out[idx] = v;
+        if (c <= r)
+            inv_out[idx] = ((r >> 4) == (c >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + (c & 15)] : S[c * DP + r];
     }
 }
 
@@ -340,7 +357,13 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse) {
     const size_t sq = (size_t)n * ld * sizeof(double);
     HIPCHK(hipMalloc(&L, sq));
     HIPCHK(hipMalloc(&invd, (size_t)(n / 128) * 16384 * sizeof(double)));
+    HIPCHK(hipMemset(invd, 0, (size_t)(n / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
+    {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, greatest));
+    }
     if (with_inverse) {
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
@@ -356,63 +379,114 @@ void DenseSolver::release() {
     hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(T);
     for (auto ev : prof_ev) hipEventDestroy(ev);
     prof_ev.clear();
+    for (auto ev : sync_ev) hipEventDestroy(ev);
+    sync_ev.clear();
+    if (pstream) hipStreamDestroy(pstream);
+    pstream = nullptr;
     L = invd = W = Q = T = nullptr;
     d_info = nullptr;
     owns = false;
 }
 
-// Two-level right-looking Cholesky.  Outer panels of `nbo` columns (trailing update with K = nbo: enough flops per
-// byte of C to be MFMA-bound), inside a panel a left-looking sweep over 128-column blocks:
+// Two-level right-looking Cholesky with one-panel lookahead.
+// Outer panels of `nbo` columns (trailing update with K = nbo: enough flops per byte of C to be MFMA-bound); inside a
+// panel a left-looking sweep over 128-column blocks:
 //   block column kk -= L[kk:n, k0:kk] L[kk:kk+128, k0:kk]'     (fp64 MFMA GEMM, K grows to nbo-128)
 //   diagonal block factor + inverse (one workgroup, LDS)        L21 = A21 inv(L11)'  (GEMM with the inverse)
+// Lookahead: the trailing update of panel s is split into (a) the columns of panel s+1 and (b) the rest; panel s+1 is
+// factored on a second, high-priority stream as soon as (a) is done, while (b) keeps the chip busy.
+hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
+    for (int k = K0; k < K1; k++) {
+        double *Akk = L + (long)(k * 128) * ld + k * 128;
+        const int rows_k = n - k * 128;
+        if (k > K0) {
+            GemmArgs c{};
+            c.A = L + (long)(k * 128) * ld + K0 * 128; c.lda = ld;      // L[k*128:n, K0*128 : k*128]
+            c.B = c.A; c.ldb = ld;                                       // first 128 rows of the same strip
+            c.C = Akk; c.ldc = ld; c.M = rows_k; c.N = 128; c.K = (k - K0) * 128;
+            c.alpha = -1.0; c.beta = 1.0; c.lower_only = 0; c.kmode = KMODE_FULL;
+            HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, c));
+        }
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, ld, invd + (long)k * 16384, d_info, k);
+        const int rows = rows_k - 128;
+        if (rows <= 0) break;
+        double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
+        GemmArgs g{};
+        // L21 = A21 * inv(L11)'   (in place: one column tile, every workgroup reads and writes only its own rows)
+        g.A = A21; g.lda = ld; g.B = invd + (long)k * 16384; g.ldb = 128; g.C = A21; g.ldc = ld;
+        g.M = rows; g.N = 128; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0; g.kmode = KMODE_FULL;
+        HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, g));
+    }
+    return hipGetLastError();
+}
+
+hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flops) {
+    if (profile) {
+        if (prof_used + 2 > prof_ev.size()) {
+            hipEvent_t a, b;
+            HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+            prof_ev.push_back(a); prof_ev.push_back(b);
+        }
+        HIPCHK(hipEventRecord(prof_ev[prof_used], st));
+    }
+    HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, u));
+    if (profile) {
+        HIPCHK(hipEventRecord(prof_ev[prof_used + 1], st));
+        prof_flops.push_back(flops);
+        prof_used += 2;
+    }
+    return hipSuccess;
+}
+
 hipError_t DenseSolver::potrf() {
     const int nb = n / 128;
     const int bo = nbo / 128 > 0 ? nbo / 128 : 1;
+    const int S = (nb + bo - 1) / bo;
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
-    for (int K0 = 0; K0 < nb; K0 += bo) {
-        const int K1 = K0 + bo < nb ? K0 + bo : nb;
-        for (int k = K0; k < K1; k++) {
-            double *Akk = L + (long)(k * 128) * ld + k * 128;
-            const int rows_k = n - k * 128;
-            if (k > K0) {
-                GemmArgs c{};
-                c.A = L + (long)(k * 128) * ld + K0 * 128; c.lda = ld;      // L[k*128:n, K0*128 : k*128]
-                c.B = c.A; c.ldb = ld;                                       // first 128 rows of the same strip
-                c.C = Akk; c.ldc = ld; c.M = rows_k; c.N = 128; c.K = (k - K0) * 128;
-                c.alpha = -1.0; c.beta = 1.0; c.lower_only = 0; c.kmode = KMODE_FULL;
-                HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, c));
-            }
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, stream, Akk, ld, invd + (long)k * 16384, d_info, k);
-            const int rows = rows_k - 128;
-            if (rows <= 0) break;
-            double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
-            GemmArgs g{};
-            // L21 = A21 * inv(L11)'   (in place: one column tile, every workgroup reads and writes only its own rows)
-            g.A = A21; g.lda = ld; g.B = invd + (long)k * 16384; g.ldb = 128; g.C = A21; g.ldc = ld;
-            g.M = rows; g.N = 128; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0; g.kmode = KMODE_FULL;
-            HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, g));
+    const bool la = lookahead && pstream != nullptr && S > 1;
+    while ((int)sync_ev.size() < 2 * S + 2) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sync_ev.push_back(e);
+    }
+    hipStream_t sp = la ? pstream : stream;
+    if (la) {
+        HIPCHK(hipEventRecord(sync_ev[2 * S], stream));
+        HIPCHK(hipStreamWaitEvent(sp, sync_ev[2 * S], 0));
+    }
+    HIPCHK(panel(sp, 0, bo < nb ? bo : nb));
+    if (la) HIPCHK(hipEventRecord(sync_ev[0], sp));
+    for (int s = 0; s < S; s++) {
+        const int K0 = s * bo, K1 = (K0 + bo < nb) ? K0 + bo : nb;
+        if (K1 >= nb) break;
+        const int K2 = (K1 + bo < nb) ? K1 + bo : nb;     // end of the next panel
+        if (la) HIPCHK(hipStreamWaitEvent(stream, sync_ev[2 * s], 0));
+        const int Kw = (K1 - K0) * 128;
+        // (a) columns of the next panel: rows >= K1, cols [K1,K2)
+        GemmArgs a{};
+        a.A = L + (long)(K1 * 128) * ld + K0 * 128; a.lda = ld; a.B = a.A; a.ldb = ld;
+        a.C = L + (long)(K1 * 128) * ld + K1 * 128; a.ldc = ld;
+        a.M = n - K1 * 128; a.N = (K2 - K1) * 128; a.K = Kw; a.alpha = -1.0; a.beta = 1.0; a.lower_only = 0; a.kmode = KMODE_FULL;
+        HIPCHK(timed_gemm(stream, a, 2.0 * Kw * ((double)a.M * a.N - 0.5 * (double)a.N * (a.N - 1))));
+        if (la) {
+            HIPCHK(hipEventRecord(sync_ev[2 * s + 1], stream));
+            HIPCHK(hipStreamWaitEvent(sp, sync_ev[2 * s + 1], 0));
         }
-        const int rows = n - K1 * 128;
-        if (rows <= 0) break;
-        // trailing update: A22 -= L21 * L21'  (lower tiles), K = width of the outer panel
-        GemmArgs u{};
-        u.A = L + (long)(K1 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
-        u.C = L + (long)(K1 * 128) * ld + K1 * 128; u.ldc = ld;
-        u.M = rows; u.N = rows; u.K = (K1 - K0) * 128; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
-        if (profile) {
-            if (prof_used + 2 > prof_ev.size()) {
-                hipEvent_t a, b;
-                HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-                prof_ev.push_back(a); prof_ev.push_back(b);
-            }
-            HIPCHK(hipEventRecord(prof_ev[prof_used], stream));
+        HIPCHK(panel(sp, K1, K2));
+        if (la) HIPCHK(hipEventRecord(sync_ev[2 * (s + 1)], sp));
+        // (b) the rest of the trailing matrix: rows, cols >= K2 (lower tiles)
+        const int rows = n - K2 * 128;
+        if (rows > 0) {
+            GemmArgs u{};
+            u.A = L + (long)(K2 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
+            u.C = L + (long)(K2 * 128) * ld + K2 * 128; u.ldc = ld;
+            u.M = rows; u.N = rows; u.K = Kw; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
+            HIPCHK(timed_gemm(stream, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
         }
-        HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, u));
-        if (profile) {
-            HIPCHK(hipEventRecord(prof_ev[prof_used + 1], stream));
-            prof_flops.push_back((double)rows * ((double)rows + 1.0) * (double)u.K);
-            prof_used += 2;
-        }
+    }
+    if (la) {   // the main stream continues only after the last panel
+        HIPCHK(hipEventRecord(sync_ev[2 * S + 1], sp));
+        HIPCHK(hipStreamWaitEvent(stream, sync_ev[2 * S + 1], 0));
     }
     return hipGetLastError();
 }
