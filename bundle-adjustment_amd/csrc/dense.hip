@@ -93,19 +93,34 @@ __device__ __forceinline__ void diag_update_tile(double *S, int R, int Q, int c0
 }
 
 // inv_out must be zero above the diagonal on entry (the buffer is zero-filled once at allocation).
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, double *inv_out, int *info, int blk) {
+__global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, double *inv_out, int *info, int blk, int dbg) {
     __shared__ double S[128 * DP];
     __shared__ double Wd[8 * 16 * WDP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        S[r * DP + c] = (c <= r) ? A[(long)r * ld + c] : 0.0;
+    // block -> LDS: 16 independent 16-byte loads in flight per thread (a rolled load->store loop serialises on the
+    // memory latency: 64 round trips, ~45 us)
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        d2_t buf[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx2 = tid + 256 * (16 * half + i);
+            buf[i] = *reinterpret_cast<const d2_t *>(A + (long)(idx2 >> 6) * ld + 2 * (idx2 & 63));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx2 = tid + 256 * (16 * half + i);
+            const int r = idx2 >> 6, c = 2 * (idx2 & 63);
+            S[r * DP + c] = (c <= r) ? buf[i].x : 0.0;
+            S[r * DP + c + 1] = (c + 1 <= r) ? buf[i].y : 0.0;
+        }
     }
     __syncthreads();
-    if (wave == 0) chol16_inv(S, Wd, 0, lane, info, blk);
+    if (wave == 0 && !(dbg & 1)) chol16_inv(S, Wd, 0, lane, info, blk);
     __syncthreads();
     for (int p = 0; p < 8; p++) {
+        if (dbg & 2) break;
         const int c0 = 16 * p;
         // ---- panel solve: L21 = A21 * Wdd' for the row tiles below ------------------------------------------
         for (int R = p + 1 + wave; R < 8; R += 4) {
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
         __syncthreads();
         // ---- phase B: wave 0 factors the next diagonal block while waves 1-3 finish the trailing update ----
         if (wave == 0) {
-            chol16_inv(S, Wd + (p + 1) * 16 * WDP, 16 * (p + 1), lane, info, blk);
+            if (!(dbg & 1)) chol16_inv(S, Wd + (p + 1) * 16 * WDP, 16 * (p + 1), lane, info, blk);
         } else {
             const int rem = 6 - p, nt = rem * (rem + 1) / 2;     // tiles (R,Q), p+2 <= Q <= R <= 7
             for (int t = wave - 1; t < nt; t += 3) {
@@ -137,13 +152,21 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
         }
         __syncthreads();
     }
-    // factor back to global (lower part)
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        if (c <= r) A[(long)r * ld + c] = S[r * DP + c];
+    // factor back to global (lower part; the strict upper part of a diagonal block is never read by anyone)
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        const int idx2 = tid + 256 * i;
+        const int r = idx2 >> 6, c = 2 * (idx2 & 63);
+        if (c <= r) {
+            d2_t v;
+            v.x = S[r * DP + c];
+            v.y = S[r * DP + c + 1];
+            *reinterpret_cast<d2_t *>(A + (long)r * ld + c) = v;
+        }
     }
     // ---- inverse, one block diagonal after the other ---------------------------------------------------------
     for (int t = 1; t < 8; t++) {
+        if (dbg & 4) break;
         for (int J = wave; J < 8 - t; J += 4) {
             const int I = J + t;
             d4_t acc = {0.0, 0.0, 0.0, 0.0};
@@ -172,10 +195,18 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
         }
         __syncthreads();
     }
-    for (int idx = tid; idx < 128 * 128; idx += 256) {
-        const int r = idx >> 7, c = idx & 127;
-        if (c <= r)
-            inv_out[idx] = ((r >> 4) == (c >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + (c & 15)] : S[c * DP + r];
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        const int idx2 = tid + 256 * i;
+        const int r = idx2 >> 6, c = 2 * (idx2 & 63);
+        if (c <= r) {
+            d2_t v;
+            v.x = ((r >> 4) == (c >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + (c & 15)] : S[c * DP + r];
+            v.y = (c + 1 > r) ? 0.0
+                              : (((r >> 4) == ((c + 1) >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + ((c + 1) & 15)]
+                                                              : S[(c + 1) * DP + r]);
+            *reinterpret_cast<d2_t *>(inv_out + r * 128 + c) = v;
+        }
     }
 }
 
@@ -407,7 +438,7 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
             c.alpha = -1.0; c.beta = 1.0; c.lower_only = 0; c.kmode = KMODE_FULL;
             HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, c));
         }
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, ld, invd + (long)k * 16384, d_info, k);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, ld, invd + (long)k * 16384, d_info, k, 0);
         const int rows = rows_k - 128;
         if (rows <= 0) break;
         double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
@@ -567,6 +598,69 @@ int DenseSolver::fetch_info() {
     if (hipMemcpyAsync(&h, d_info, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
     return h;
+}
+
+// fp64 MFMA issue-rate ceiling: every wave runs `iters` x 16 independent v_mfma_f64_16x16x4 on register operands
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double *out, int iters) {
+    d4_t acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 123.456) out[0] = s;
+}
+
+hipError_t mfma_peak_bench(int blocks, int iters, float *ms_out, double *tflops) {
+    double *out = nullptr;
+    HIPCHK(hipMalloc(&out, 8));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, out, iters);
+    hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, nullptr, out, iters);
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(ms_out, e0, e1);
+    *tflops = (double)blocks * 4.0 * iters * 16.0 * 2048.0 / (*ms_out * 1e-3) / 1e12;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(out);
+    return hipGetLastError();
+}
+
+// timing hook for the diagonal-block kernel (diagnostics): `iters` back-to-back launches on an SPD 128x128 block
+hipError_t diag_kernel_bench(int dbg, int iters, float *ms_out) {
+    double *A = nullptr, *inv = nullptr;
+    int *info = nullptr;
+    HIPCHK(hipMalloc(&A, 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&inv, 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&info, sizeof(int)));
+    double *h = new double[16384];
+    for (int r = 0; r < 128; r++)
+        for (int c = 0; c < 128; c++) h[r * 128 + c] = (r == c) ? 4.0 : 0.5 / (1.0 + (r > c ? r - c : c - r));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipMemset(inv, 0, 16384 * sizeof(double));
+    hipMemset(info, 0, sizeof(int));
+    hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; i++) {
+        hipMemcpyAsync(A, h, 16384 * sizeof(double), hipMemcpyHostToDevice, nullptr);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, nullptr, A, 128L, inv, info, 0, dbg);
+    }
+    hipEventRecord(e1, nullptr);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(ms_out, e0, e1);
+    *ms_out /= iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(A); hipFree(inv); hipFree(info);
+    delete[] h;
+    return hipGetLastError();
 }
 
 }  // namespace jaicov

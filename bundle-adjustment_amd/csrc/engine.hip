@@ -1051,6 +1051,20 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
     return status;
 }
 
+namespace jaicov { hipError_t diag_kernel_bench(int dbg, int iters, float *ms_out); hipError_t mfma_peak_bench(int, int, float *, double *); }
+extern "C" int jaicov_debug_mfma_peak(int blocks, int iters, double *ms_out, double *tflops) {
+    float ms = 0;
+    hipError_t he = jaicov::mfma_peak_bench(blocks, iters, &ms, tflops);
+    *ms_out = ms;
+    return he == hipSuccess ? 0 : -5;
+}
+extern "C" int jaicov_debug_diag_bench(int dbg, int iters, double *ms_out) {
+    float ms = 0;
+    hipError_t he = jaicov::diag_kernel_bench(dbg, iters, &ms);
+    *ms_out = ms;
+    return he == hipSuccess ? 0 : -5;
+}
+
 // C (M x N row-major) = alpha * op(A) op(B) + beta * C on the device, host buffers in/out (kernel parity + timing)
 extern "C" int jaicov_dense_gemm(int32_t alay, int32_t blay, int32_t M, int32_t N, int32_t K, double alpha, const double *A,
                                  int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
