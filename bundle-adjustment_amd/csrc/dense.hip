@@ -605,8 +605,17 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double *out, int iters) 
     d4_t acc[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    // iters < 0: random full-mantissa operands that change every iteration (DVFS: zero/constant data clocks higher)
+    const bool rnd = iters < 0;
+    if (rnd) iters = -iters;
+    unsigned long long st = 0x9E3779B97F4A7C15ull * (threadIdx.x + 1 + 256ull * blockIdx.x);
     double a = 1.0 + 1e-9 * threadIdx.x, b = 1.0 - 1e-9 * threadIdx.x;
     for (int it = 0; it < iters; it++) {
+        if (rnd) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            a = __longlong_as_double((long long)((st >> 12) | 0x3FF0000000000000ull)) - 1.5;
+            b = __longlong_as_double((long long)(((st * 0x2545F4914F6CDD1Dull) >> 12) | 0x3FF0000000000000ull)) - 1.5;
+        }
 #pragma unroll
         for (int i = 0; i < 16; i++)
             asm volatile("v_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
@@ -628,7 +637,7 @@ hipError_t mfma_peak_bench(int blocks, int iters, float *ms_out, double *tflops)
     hipEventRecord(e1, nullptr);
     hipEventSynchronize(e1);
     hipEventElapsedTime(ms_out, e0, e1);
-    *tflops = (double)blocks * 4.0 * iters * 16.0 * 2048.0 / (*ms_out * 1e-3) / 1e12;
+    *tflops = (double)blocks * 4.0 * (iters < 0 ? -iters : iters) * 16.0 * 2048.0 / (*ms_out * 1e-3) / 1e12;
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(out);
     return hipGetLastError();

@@ -1069,6 +1069,7 @@ extern "C" int jaicov_debug_diag_bench(int dbg, int iters, double *ms_out) {
 extern "C" int jaicov_dense_gemm(int32_t alay, int32_t blay, int32_t M, int32_t N, int32_t K, double alpha, const double *A,
                                  int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,
                                  int32_t lower_only, int32_t kmode, int32_t repeats, double *ms_out) {
+
     if (M % 128 || N % 128 || K % 16 || M <= 0 || N <= 0 || K <= 0 || !A || !B || !C) return JAICOV_ERR_BAD_ARGUMENT;
     std::string err;
     int rc = check_device(err);
