@@ -1,0 +1,201 @@
+"""Host mirror of JAICOV's object API (C++ / pybind11): index contract (CPU) and estimateModel() on the GPU.
+
+Config 1 of BASELINE.json: the bundled example block (115 images, 150 points, 9 972 image points, 1 scale bar)."""
+import gzip
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import numbering
+from bundle_adjustment_amd.problem import packed_to_full
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example")
+
+
+@pytest.fixture(scope="module")
+def H():
+    from bundle_adjustment_amd import host_api
+    return host_api
+
+
+@pytest.fixture()
+def example_base(tmp_path):
+    for f in ("ior", "eor", "obc", "scale"):
+        shutil.copy(os.path.join(GOLDEN, f"example.{f}"), tmp_path)
+    with gzip.open(os.path.join(GOLDEN, "example.phc.gz")) as src, open(tmp_path / "example.phc", "wb") as dst:
+        dst.write(src.read())
+    return str(tmp_path / "example")
+
+
+def example_adjustment(H, base, unit_weights=False):
+    """ExampleReport.java:61-89 on the flat files: A3, Cx, Cy fixed (example.htm:83,86-87), datum = names <= 3 chars."""
+    pr = H.read_aicon_flat(base)
+    cam = pr.camera
+    cam.getDistortionModel(H.DistortionModelType.RADIAL_DISTORTION).get(3).setColumn(H.COLUMN_FIXED)
+    aff = cam.getDistortionModel(H.DistortionModelType.AFFINITY_AND_SHEAR)
+    aff.getCx().setColumn(H.COLUMN_FIXED); aff.getCy().setColumn(H.COLUMN_FIXED)
+    for p in pr.points():
+        if len(p.getName()) > 3:
+            p.setDatum(False)
+    if unit_weights:   # config 1 "identity dispersion": all variances 1 -> sigma0^2 = 1, P = I
+        for im in cam.images():
+            for ic in im.coordinates():
+                ic.getX().setVariance(1.0); ic.getY().setVariance(1.0)
+        for s in pr.scaleBars():
+            s.getLength().setVariance(1.0)
+    ba = H.BundleAdjustment()
+    ba.add(cam)
+    for s in pr.scaleBars():
+        ba.add(s)
+    ba.setInvertNormalEquation(H.MatrixInversion.FULL)
+    return pr, ba
+
+
+def test_example_index_known_answers(H, example_base):
+    """SURVEY.md Appendix B / example.htm:33-35,42: n = 19 945, u = 1 147, d = 6, dof = 18 804 and the column layout."""
+    pr, ba = example_adjustment(H, example_base)
+    ba.prepareUnknownParameters()
+    ba.flatten()
+    cam = pr.camera
+    assert cam.getNumberOfImages() == 115 and len(pr.points()) == 150 and len(pr.scaleBars()) == 1
+    assert ba.getNumberOfObservations() == 19945
+    assert ba.getNumberOfUnknownParameters() == 1147
+    assert ba.getNumberOfDatumConditions() == 6
+    assert ba.getDegreeOfFreedom() == 18804
+    assert ba.getDatumFlags() == 1 + 2 + 4 + 8 + 16 + 32          # tx,ty,tz,rx,ry,rz free; scale fixed by the scale bar
+    io = cam.getInteriorOrientation()
+    assert [io.getPrinciplePointX().getColumn(), io.getPrinciplePointY().getColumn(), io.getPrincipleDistance().getColumn()] == [456, 457, 458]
+    tan = cam.getDistortionModel(H.DistortionModelType.TANGENTIAL_DISTORTION)
+    rad = cam.getDistortionModel(H.DistortionModelType.RADIAL_DISTORTION)
+    assert [tan.getBx().getColumn(), tan.getBy().getColumn()] == [459, 460]
+    assert [rad.get(1).getColumn(), rad.get(2).getColumn(), rad.get(3).getColumn()] == [461, 462, H.COLUMN_FIXED]
+    pts = ba.getObjectCoordinates()
+    assert [p.getName() for p in pts[:6]] == ["6", "14", "15", "17", "18", "25"]
+    assert [pts[0].getX().getColumn(), pts[0].getY().getColumn(), pts[0].getZ().getColumn()] == [6, 7, 8]
+    assert pts[-1].getZ().getColumn() == 455
+    imgs = cam.images()
+    assert imgs[0].getExteriorOrientation().get(H.ParameterType.CAMERA_COORDINATE_X).getColumn() == 463
+    assert imgs[-1].getExteriorOrientation().get(H.ParameterType.CAMERA_KAPPA).getColumn() == 1152
+    assert sum(p.isDatum() for p in pts) == 66
+    d = ba.flat()
+    # rows: image points first (x then y, image-major), scale bar last
+    assert imgs[0].coordinates()[0].getX().getRow() == 0 and pr.scaleBars()[0].getLength().getRow() == 19944
+    assert abs(d["sigma2apriori"] - min(d["ip_var_x"].min(), d["ip_var_y"].min(), d["sb_var"].min(), 1.0)) == 0
+
+
+def test_cpp_numbering_matches_python_numbering(H, example_base):
+    pr, ba = example_adjustment(H, example_base)
+    ba.prepareUnknownParameters(); ba.flatten()
+    d = ba.flat()
+    P = d["point_col"].size // 3
+    num = numbering.number_unknowns(P, 1, d["image_camera"], d["ip_point"], d["cam_dist_begin"],
+                                    dist_fixed=d["dist_col"] < 0, sb_point_a=d["sb_point_a"], sb_point_b=d["sb_point_b"])
+    np.testing.assert_array_equal(num["point_col"].ravel(), d["point_col"])
+    np.testing.assert_array_equal(num["io_col"].ravel(), d["io_col"])
+    np.testing.assert_array_equal(num["dist_col"], d["dist_col"])
+    np.testing.assert_array_equal(num["eo_col"].ravel(), d["eo_col"])
+    assert num["n_unknowns"] == d["n_unknowns"] and num["datum_flags"] == d["datum_flags"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_rank_defect_literal_vs_closed_form(H, seed):
+    """BundleAdjustment.detectRankDefect: the loop-by-loop C++ mirror vs the closed form used by the flat generators."""
+    rng = np.random.default_rng(seed)
+    T = H.DistortionModelType
+    cam = H.Camera(1, 10.0, [T.RADIAL_DISTORTION])
+    pts = [H.ObjectCoordinate(str(i), *rng.normal(0, 100, 3)) for i in range(8)]
+    imgs = [cam.add(i) for i in range(3)]
+    for im in imgs:
+        for p in pts:
+            im.add(p, 0.1, 0.2, 0.001, 0.001)
+    # random fixed coordinates / angles
+    point_fixed = np.zeros((8, 3), bool); eo_fixed = np.zeros((3, 6), bool)
+    PT = H.ParameterType
+    eo_types = [PT.CAMERA_COORDINATE_X, PT.CAMERA_COORDINATE_Y, PT.CAMERA_COORDINATE_Z, PT.CAMERA_OMEGA, PT.CAMERA_PHI, PT.CAMERA_KAPPA]
+    for _ in range(rng.integers(0, 4)):
+        i, a = rng.integers(0, 8), rng.integers(0, 3)
+        [pts[i].getX(), pts[i].getY(), pts[i].getZ()][a].setColumn(H.COLUMN_FIXED); point_fixed[i, a] = True
+    for _ in range(rng.integers(0, 3)):
+        i, a = rng.integers(0, 3), rng.integers(0, 6)
+        imgs[i].getExteriorOrientation().get(eo_types[a]).setColumn(H.COLUMN_FIXED); eo_fixed[i, a] = True
+    ba = H.BundleAdjustment(); ba.add(cam)
+    sb = []
+    if rng.random() < 0.5:
+        sb = [H.ScaleBar(pts[0], pts[1], 10.0, 0.01)]; ba.add(sb[0])
+    obs, kinds = [], []
+    for _ in range(rng.integers(0, 5)):
+        i, a = int(rng.integers(0, 8)), int(rng.integers(0, 3))
+        up = [pts[i].getX(), pts[i].getY(), pts[i].getZ()][a]
+        if up.getColumn() == H.COLUMN_FIXED or any(o[1] is up for o in obs):
+            continue
+        o = H.ObservationParameter(up); o.setVariance(1e-4); obs.append((o, up)); kinds.append("XYZ"[a])
+    grp = None
+    if obs:
+        grp = H.DirectlyObservedParameterGroup([o for o, _ in obs]); ba.add(grp)
+    ba.prepareUnknownParameters()
+    n_fixed = point_fixed.sum(0) + eo_fixed[:, :3].sum(0)
+    flags = numbering.detect_rank_defect(bool(sb), kinds, n_fixed, eo_fixed[:, 3:].any(0))
+    assert ba.getDatumFlags() == flags
+
+
+def test_example_oracle_known_answers(H, example_base, oracle_mod):
+    """Pins the oracle on the reference's only third-party known answers (SURVEY.md 8c ii): with the protocol's uniform
+    a-priori sigma 0.0005 mm (example.htm:31) the adjustment started from AICON's adjusted values is a near fixed point
+    (converges in <= 4 passes, coordinates move by micrometres) and the a-posteriori S0 reproduces AICON's 0.000405."""
+    pr, ba = example_adjustment(H, example_base)
+    for im in pr.camera.images():
+        for ic in im.coordinates():
+            ic.getX().setVariance(0.0005 ** 2); ic.getY().setVariance(0.0005 ** 2)
+    ba.prepareUnknownParameters(); ba.flatten()
+    from bundle_adjustment_amd.host_api import flat_problem
+    fp = flat_problem(ba).validate()
+    v, Q, res = oracle_mod.Oracle(fp).estimate(invert=False)
+    assert res.state == 1 and res.iterations <= 4
+    s0 = np.sqrt(res.omega / fp.degree_of_freedom)
+    assert abs(s0 - 0.000405) < 1.5e-6, s0
+    assert np.abs(v - fp.values)[:3 * fp.n_points].max() < 0.01     # mm
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("unit_weights", [False, True])
+def test_example_estimate_model_matches_oracle(H, example_base, oracle_mod, unit_weights):
+    """BundleAdjustment.estimateModel() through the C++ host + C ABI on the MI355X vs the CPU oracle on the same flat
+    problem: adjusted parameters 1e-9 relative, cofactor diagonal 1e-8, identical iteration count."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr0, ba0 = example_adjustment(H, example_base, unit_weights)
+    ba0.useCentroidedCoordinates(False)
+    ba0.prepareUnknownParameters(); ba0.flatten()
+    fp = flat_problem(ba0).validate()
+    vo, Qo, ro = oracle_mod.Oracle(fp).estimate()
+    pr, ba = example_adjustment(H, example_base, unit_weights)
+    ba.useCentroidedCoordinates(False)
+    events = []
+    ba.addPropertyChangeListener(lambda n, a, b: events.append(n))
+    state = ba.estimateModel()
+    assert state == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+    assert ro.state == 1 and ba.getIterations() == ro.iterations
+    assert "INVERT_NORMAL_EQUATION_MATRIX" in events and events[-1] == "ERROR_FREE_ESTIMATION"
+    pts = ba.getObjectCoordinates()
+    got = np.array([[p.getX().getValue(), p.getY().getValue(), p.getZ().getValue()] for p in pts]).ravel()
+    ref = vo[:got.size]
+    assert (np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-9
+    assert abs(ba.getOmega() - ro.omega) < 1e-8 * ro.omega
+    assert abs(ba.getVarianceFactorAposteriori() - ro.omega / fp.degree_of_freedom) < 1e-8 * ro.omega / fp.degree_of_freedom
+    Q = ba.getCofactorMatrix()
+    U, d = fp.n_unknowns, fp.rank_defect
+    dq = np.diag(packed_to_full(Q, U))[d:]; dqo = np.diag(packed_to_full(Qo, U))[d:]
+    np.testing.assert_allclose(dq, dqo, rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_example_centroided_equals_uncentroided(H, example_base):
+    """useCentroidedCoordinates (BundleAdjustment.java:115-201) must not change the adjusted coordinates."""
+    res = []
+    for cen in (True, False):
+        pr, ba = example_adjustment(H, example_base)
+        ba.useCentroidedCoordinates(cen)
+        assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+        res.append(np.array([[p.getX().getValue(), p.getY().getValue(), p.getZ().getValue()] for p in ba.getObjectCoordinates()]))
+    assert np.abs(res[0] - res[1]).max() < 1e-6
