@@ -38,13 +38,6 @@ def parse():
     return ap.parse_args()
 
 
-class _DevArray:
-    """Exposes a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline(fp, eng, sigma2):
     """CPU restatement (oracle, single thread) on a bounded sample of the same workload, extrapolated to one pass.
 
@@ -112,11 +105,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29512")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from bundle_adjustment_amd import engine, scene
+    from bundle_adjustment_amd import distributed, engine, scene
 
     fp = scene.config(a.config)
-    I = fp.n_images
-    lo, hi = (rank * I) // world, ((rank + 1) * I) // world
+    lo, hi = distributed.partition_images(fp, world)[rank]
     eng = engine.Engine(fp, device=local, image_range=(lo, hi) if use_dist else None, apply_shared=(rank == 0))
     eng.set_parameters(fp.values)
     s2 = fp.sigma2apriori
@@ -124,10 +116,7 @@ def main():
     def step():
         if use_dist:
             eng.accumulate(s2)
-            ptr, cnt = eng.reduce_buffer()
-            buf = torch.as_tensor(_DevArray(ptr, cnt), device=torch.device("cuda", local))
-            dist.all_reduce(buf)
-            torch.cuda.synchronize()
+            distributed.allreduce_engine_buffer(eng, dist, torch.device("cuda", local))
             eng.finalize(s2, 0.0)
         else:
             eng.build(s2, 0.0)
@@ -190,9 +179,9 @@ def main():
         sync()
         t1 = time.perf_counter()
         if use_dist:
-            eng.accumulate(s2); ptr, cnt = eng.reduce_buffer()
-            buf = torch.as_tensor(_DevArray(ptr, cnt), device=torch.device("cuda", local)); dist.all_reduce(buf)
-            torch.cuda.synchronize(); eng.finalize(s2, 0.0)
+            eng.accumulate(s2)
+            distributed.allreduce_engine_buffer(eng, dist, torch.device("cuda", local))
+            eng.finalize(s2, 0.0)
         else:
             eng.build(s2, 0.0)
         dx = eng.solve(True)

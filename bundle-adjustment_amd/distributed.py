@@ -1,0 +1,65 @@
+"""Multi-GPU plumbing: shard observation groups by image, one all-reduce of the packed normal equations per pass.
+
+SURVEY.md 8(e): W is block-diagonal by image, so N = sum_rank N_rank and n = sum_rank n_rank.  Every rank holds the
+whole (small) structure and all parameter values, accumulates the image range it owns, the packed buffer
+[N (U(U+1)/2) | n (U)] is summed in place with ``torch.distributed.all_reduce`` (backend "nccl" == RCCL over xGMI on
+MI355X; "gloo" in the CPU rehearsal), and every rank then applies datum/damping/preconditioner and solves the
+identical system.  Scale bars and directly observed groups are contributed by rank 0 only.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def image_costs(fp) -> np.ndarray:
+    """Relative assembly cost per image: m_g^2 * k_g for a dense image block, n_obs * k^2 otherwise."""
+    I = fp.n_images
+    counts = np.bincount(fp.ip_image, minlength=I).astype(np.float64)
+    k = 12.0 + np.diff(fp.cam_dist_begin)[fp.image_camera]
+    cost = counts * k * k
+    for b in range(fp.n_image_blocks):
+        lo, hi = int(fp.blk_ip_begin[b]), int(fp.blk_ip_begin[b + 1])
+        if hi > lo:
+            img = int(fp.ip_image[lo])
+            m = 2.0 * (hi - lo)
+            cost[img] = m * m * (3 * (hi - lo) + k[img])
+    return cost
+
+
+def partition_images(fp, world: int):
+    """Contiguous image ranges [lo, hi) per rank, balanced by ``image_costs`` (prefix-sum split)."""
+    cost = image_costs(fp)
+    csum = np.concatenate([[0.0], np.cumsum(cost)])
+    total = csum[-1]
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r / world
+        b = int(np.searchsorted(csum, target, side="left"))
+        b = min(max(b, bounds[-1]), fp.n_images)
+        bounds.append(b)
+    bounds.append(fp.n_images)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+class DeviceArray:
+    """Raw device pointer as a torch-visible array (``__cuda_array_interface__``, no copy)."""
+
+    def __init__(self, ptr: int, count: int):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+
+def allreduce_engine_buffer(eng, dist, device):
+    """Sums the engine's packed partial normal equations over all ranks, in place on the device."""
+    import torch
+    ptr, cnt = eng.reduce_buffer()
+    buf = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
+    dist.all_reduce(buf)
+    torch.cuda.synchronize(device)
+
+
+def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
+    """One pass of the loop body on a sharded engine: accumulate -> all-reduce -> finalize -> solve."""
+    eng.accumulate(sigma2)
+    allreduce_engine_buffer(eng, dist, device)
+    eng.finalize(sigma2, lam)
+    return eng.solve(invert)

@@ -191,3 +191,26 @@ def test_medium_config2_against_oracle(oracle_mod):
     dq = np.diag(packed_to_full(Q, U)); dqo = np.diag(packed_to_full(Qo, U))
     np.testing.assert_allclose(dq, dqo, rtol=1e-9)
     eng.close()
+
+
+def test_rccl_reduce_path_world1(oracle_mod):
+    """The collective path on one GPU: accumulate -> all_reduce (backend nccl == RCCL) on the engine's device buffer ->
+    finalize -> solve must reproduce the plain build + solve."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from bundle_adjustment_amd import distributed
+    fp = scene.config("tiny_block")
+    s2 = fp.sigma2apriori
+    ref = engine.Engine(fp); ref.set_parameters(fp.values); ref.build(s2); dx_ref = ref.solve(False); ref.close()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        lo, hi = distributed.partition_images(fp, 1)[0]
+        eng = engine.Engine(fp, image_range=(lo, hi), apply_shared=True)
+        eng.set_parameters(fp.values)
+        dx = distributed.sharded_step(eng, dist, torch.device("cuda", 0), s2)
+        np.testing.assert_allclose(dx, dx_ref, rtol=0, atol=1e-12 * np.abs(dx_ref).max())
+        eng.close()
+    finally:
+        dist.destroy_process_group()
