@@ -256,10 +256,65 @@ __global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t
 // Inside one image all q are distinct points, so the LDS updates never collide; a barrier separates images.  The strip
 // is added to N (lower part, c <= r) once at the end: every entry of the point-point block has exactly one owner, the
 // sum order is fixed (images ascending) -> bitwise reproducible, no memory-side atomics.
+// The walk is software-pipelined: the loads of image o+1 (one 32-byte record, then Dinv rows / columns / Jacobian rows
+// of up to 512 points, two per thread) are in flight while image o is accumulated.
 constexpr int PP_CW = 4992;
+
+struct PPData {           // what one thread needs of one image: two points q = tid, tid + 256
+    d2_t P0[2], P1[2];
+    double aq[2][6];
+    int cq[2][3];
+    double ap0[3], ap1[3];
+};
+
+__device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PPRecord &r, const int32_t *__restrict__ ipcol,
+                                        const double *__restrict__ rowsA, double sigma2, int tid, int qbase) {
+    const long S = p.n_ip;
+    const int m = 2 * r.mp;
+    const double *P = p.blk_w + r.poff;
+    const int ip = r.ipb + r.lp;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        d.ap0[a] = sigma2 * rowsA[(long)(2 * a) * S + ip];
+        d.ap1[a] = sigma2 * rowsA[(long)(2 * a + 1) * S + ip];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int q = qbase + tid + 256 * i;
+        if (q < r.mp) {
+            d.P0[i] = *reinterpret_cast<const d2_t *>(P + (long)(2 * r.lp) * m + 2 * q);
+            d.P1[i] = *reinterpret_cast<const d2_t *>(P + (long)(2 * r.lp + 1) * m + 2 * q);
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                d.cq[i][b] = ipcol[3 * (long)(r.ipb + q) + b];
+                d.aq[i][2 * b] = rowsA[(long)(2 * b) * S + r.ipb + q];
+                d.aq[i][2 * b + 1] = rowsA[(long)(2 * b + 1) * S + r.ipb + q];
+            }
+        } else {
+            d.cq[i][0] = d.cq[i][1] = d.cq[i][2] = -1;
+        }
+    }
+}
+
+__device__ __forceinline__ void pp_accumulate(const PPData &d, double *strip, int c0, int cp0, int cp1, int cp2) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+#pragma unroll
+        for (int b = 0; b < 3; b++) {
+            const int cq = d.cq[i][b];
+            if (cq < c0 || cq >= c0 + PP_CW) continue;
+            const double g0 = d.P0[i].x * d.aq[i][2 * b] + d.P0[i].y * d.aq[i][2 * b + 1];
+            const double g1 = d.P1[i].x * d.aq[i][2 * b] + d.P1[i].y * d.aq[i][2 * b + 1];
+            if (cp0 >= cq) strip[cq - c0] += d.ap0[0] * g0 + d.ap1[0] * g1;
+            if (cp1 >= cq) strip[PP_CW + cq - c0] += d.ap0[1] * g0 + d.ap1[1] * g1;
+            if (cp2 >= cq) strip[2 * PP_CW + cq - c0] += d.ap0[2] * g0 + d.ap1[2] * g1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const int32_t *__restrict__ pt_ip_begin,
-                                                            const int32_t *__restrict__ pt_ip_list,
-                                                            const int32_t *__restrict__ blk_of_ip,
+                                                            const PPRecord *__restrict__ recs,
+                                                            const int32_t *__restrict__ ipcol,
                                                             const double *__restrict__ rowsA, double sigma2,
                                                             double *__restrict__ N, int cmin) {
     __shared__ double strip[3 * PP_CW];
@@ -270,34 +325,25 @@ __global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const 
     const int ob = pt_ip_begin[pt], oe = pt_ip_begin[pt + 1];
     if (rmax < c0 || ob == oe) return;
     for (int i = tid; i < 3 * PP_CW; i += 256) strip[i] = 0.0;
+    PPRecord rec = recs[ob];
+    PPRecord rec_next = recs[min(ob + 1, oe - 1)];
+    PPData cur, nxt;
+    pp_load(cur, p, rec, ipcol, rowsA, sigma2, tid, 0);
     __syncthreads();
-    const long S = p.n_ip;
     for (int o = ob; o < oe; o++) {
-        const int ip = pt_ip_list[o], g = blk_of_ip[ip];
-        const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb, m = 2 * mp, lp = ip - ipb;
-        const double *P = p.blk_w + p.blk_w_offset[g];
-        double ap0[3], ap1[3];
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            ap0[a] = sigma2 * rowsA[(long)(2 * a) * S + ip];
-            ap1[a] = sigma2 * rowsA[(long)(2 * a + 1) * S + ip];
-        }
-        for (int q = tid; q < mp; q += 256) {
-            const d2_t P0 = *reinterpret_cast<const d2_t *>(P + (long)(2 * lp) * m + 2 * q);
-            const d2_t P1 = *reinterpret_cast<const d2_t *>(P + (long)(2 * lp + 1) * m + 2 * q);
-            const int ptq = p.ip_point[ipb + q];
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const int cq = p.point_col[3 * ptq + b];
-                if (cq < c0 || cq >= c0 + PP_CW) continue;
-                const double aq0 = rowsA[(long)(2 * b) * S + ipb + q], aq1 = rowsA[(long)(2 * b + 1) * S + ipb + q];
-                const double g0 = P0.x * aq0 + P0.y * aq1, g1 = P1.x * aq0 + P1.y * aq1;
-                if (cp0 >= cq) strip[cq - c0] += ap0[0] * g0 + ap1[0] * g1;
-                if (cp1 >= cq) strip[PP_CW + cq - c0] += ap0[1] * g0 + ap1[1] * g1;
-                if (cp2 >= cq) strip[2 * PP_CW + cq - c0] += ap0[2] * g0 + ap1[2] * g1;
-            }
+        const PPRecord rec_after = recs[min(o + 2, oe - 1)];
+        if (o + 1 < oe) pp_load(nxt, p, rec_next, ipcol, rowsA, sigma2, tid, 0);
+        pp_accumulate(cur, strip, c0, cp0, cp1, cp2);
+        // images with more than 512 points: the remaining chunks without prefetch
+        for (int qb = 512; qb < rec.mp; qb += 512) {
+            PPData extra;
+            pp_load(extra, p, rec, ipcol, rowsA, sigma2, tid, qb);
+            pp_accumulate(extra, strip, c0, cp0, cp1, cp2);
         }
         __syncthreads();
+        cur = nxt;
+        rec = rec_next;
+        rec_next = rec_after;
     }
     const int cps[3] = {cp0, cp1, cp2};
 #pragma unroll
@@ -488,7 +534,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
                        ip_list, n_ip_list, rowsA, T, sigma2, N, n);
     if (pp.pt_ip_begin) {
         hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(256), 0, s, p, pp.pt_ip_begin,
-                           pp.pt_ip_list, pp.blk_of_ip, rowsA, sigma2, N, pp.cmin);
+                           pp.recs, pp.ipcol, rowsA, sigma2, N, pp.cmin);
     } else {
         const int mp = max_m / 2;
         hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, p, blk_list, rowsA, sigma2, N);

@@ -37,8 +37,15 @@ struct DevProblem {
 };
 
 // tables of the atomics-free point x point gather (assemble.hip, blk_pp_gather_kernel); null = use the atomic kernel
+struct PPRecord {          // one (object point, image block) incidence, 32 bytes
+    int32_t ipb, mp, lp, pad;   // first image point of the block, points in the block, local index of the point
+    int64_t poff;               // offset of the block's Dinv in blk_w
+    int64_t pad2;
+};
 struct PPGather {
-    const int32_t *pt_ip_begin = nullptr, *pt_ip_list = nullptr, *blk_of_ip = nullptr;
+    const int32_t *pt_ip_begin = nullptr;   // [n_points+1] CSR over recs
+    const PPRecord *recs = nullptr;         // image order within a point
+    const int32_t *ipcol = nullptr;         // [3*n_ip] column of X,Y,Z of the point seen by image point ip
     int cmin = 0, n_chunks = 0;
 };
 

@@ -498,7 +498,7 @@ hipError_t DenseSolver::potrf() {
         a.A = L + (long)(K1 * 128) * ld + K0 * 128; a.lda = ld; a.B = a.A; a.ldb = ld;
         a.C = L + (long)(K1 * 128) * ld + K1 * 128; a.ldc = ld;
         a.M = n - K1 * 128; a.N = (K2 - K1) * 128; a.K = Kw; a.alpha = -1.0; a.beta = 1.0; a.lower_only = 0; a.kmode = KMODE_FULL;
-        HIPCHK(timed_gemm(stream, a, 2.0 * Kw * ((double)a.M * a.N - 0.5 * (double)a.N * (a.N - 1))));
+        HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, a));
         if (la) {
             HIPCHK(hipEventRecord(sync_ev[2 * s + 1], stream));
             HIPCHK(hipStreamWaitEvent(sp, sync_ev[2 * s + 1], 0));

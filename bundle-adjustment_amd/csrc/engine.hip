@@ -391,9 +391,19 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
             }
         }
         if (cmax >= cmin) {
+            std::vector<PPRecord> recs(list.size());
+            for (size_t t = 0; t < list.size(); t++) {
+                const int ip = list[t], g = blk_of_ip[ip];
+                PPRecord r{};
+                r.ipb = D->blk_ip_begin[g]; r.mp = D->blk_ip_begin[g + 1] - r.ipb; r.lp = ip - r.ipb; r.poff = blk_w_off[g];
+                recs[t] = r;
+            }
+            std::vector<int32_t> ipcol((size_t)3 * D->n_image_points, -1);
+            for (int ip : blk_ip_list)
+                for (int a = 0; a < 3; a++) ipcol[(size_t)3 * ip + a] = D->point_col[3 * D->ip_point[ip] + a];
             if ((rc = upload(e, cnt.data(), cnt.size(), &e->pp.pt_ip_begin))) return rc;
-            if ((rc = upload(e, list.data(), list.size(), &e->pp.pt_ip_list))) return rc;
-            if ((rc = upload(e, blk_of_ip.data(), blk_of_ip.size(), &e->pp.blk_of_ip))) return rc;
+            if ((rc = upload(e, recs.data(), recs.size(), &e->pp.recs))) return rc;
+            if ((rc = upload(e, ipcol.data(), ipcol.size(), &e->pp.ipcol))) return rc;
             e->pp.cmin = cmin;
             e->pp.n_chunks = (cmax - cmin + 4992) / 4992;
         }

@@ -1,0 +1,46 @@
+"""Parses rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of bench.py and writes profiles/pmc_traffic.json.
+
+HBM bytes per launch of the dominant kernel (the lower-triangular Cholesky trailing update, gemm_f64_kernel<KC,KC> with a
+triangular grid) = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and FETCH_SIZE reports half of
+the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section); the two counters come from separate
+passes (TCC slot limit).  Usage: python scripts/pmc_traffic.py <fetch_dir> <write_dir> [U]"""
+import csv, glob, json, os, sys
+
+def dispatches(d, counter):
+    f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+    out = []
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter and "gemm_f64_kernel<0, 0>" in r["Kernel_Name"]:
+            out.append((int(r["Grid_Size"]) // 256, float(r["Counter_Value"])))
+    return out
+
+def main():
+    fetch_dir, write_dir = sys.argv[1], sys.argv[2]
+    U = int(sys.argv[3]) if len(sys.argv) > 3 else 18014
+    nb, bo = (U + 127) // 128, 4
+    # tile counts of the trailing updates (b) of csrc/dense.hip::potrf: T = nb - K2, tiles = T(T+1)/2, T >= 17 only
+    # (smaller triangular counts collide with the tile counts of the panel GEMMs)
+    tiles = set()
+    K0 = 0
+    while K0 + bo < nb:
+        K2 = min(K0 + 2 * bo, nb)
+        T = nb - K2
+        if T >= 17:
+            tiles.add(T * (T + 1) // 2)
+        K0 += bo
+    fe = [v for g, v in dispatches(fetch_dir, "FETCH_SIZE") if g in tiles]
+    wr = [v for g, v in dispatches(write_dir, "WRITE_SIZE") if g in tiles]
+    n = min(len(fe), len(wr))
+    fetch_kb, write_kb = sum(fe) / len(fe), sum(wr) / len(wr)
+    out = {"kernel": "gemm_f64_kernel<KC,KC> lower-triangular trailing update (T >= 17 tile rows)",
+           "dispatches_matched": n, "fetch_size_kib_per_launch_raw": fetch_kb, "write_size_kib_per_launch": write_kb,
+           "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+           "hbm_bytes_per_launch_uncorrected": (fetch_kb + write_kb) * 1024.0,
+           "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests as 64 B for wide coalesced reads); "
+                   "the C-tile loads are 8 B/lane, for which the guide gives no calibration, so the corrected figure is an upper bound"}
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+if __name__ == "__main__":
+    main()

@@ -11,6 +11,13 @@ for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.dirname(os.path.abspath(__
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch brings its own copy of the HIP runtime: let it initialise first so that the engine library (linked against
+    # /opt/rocm) and torch.distributed share one runtime in this process (bench.py does the same)
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
