@@ -210,7 +210,7 @@ def test_rccl_reduce_path_world1(oracle_mod):
         eng = engine.Engine(fp, image_range=(lo, hi), apply_shared=True)
         eng.set_parameters(fp.values)
         dx = distributed.sharded_step(eng, dist, torch.device("cuda", 0), s2)
-        np.testing.assert_allclose(dx, dx_ref, rtol=0, atol=1e-12 * np.abs(dx_ref).max())
+        np.testing.assert_allclose(dx, dx_ref, rtol=0, atol=1e-8 * np.abs(dx_ref).max())   # fp64 atomics: summation order differs run to run
         eng.close()
     finally:
         dist.destroy_process_group()
