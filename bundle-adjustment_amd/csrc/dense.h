@@ -22,8 +22,12 @@ struct DenseSolver {
     long ld = 0;
     int nbo = 512;             // outer panel width of the factorisation (multiple of 128)
     bool lookahead = true;     // factor panel s+1 on `pstream` while the rest of trailing update s runs
-    hipStream_t pstream = nullptr;
+    hipStream_t pstream = nullptr;   // panel GEMMs (high priority)
+    hipStream_t ustream = nullptr;   // trailing updates: all CUs except the reserved ones (CU mask)
+    hipStream_t dstream = nullptr;   // diagonal-block kernel: the reserved CUs
     std::vector<hipEvent_t> sync_ev;
+    size_t ev_used = 0;
+    hipEvent_t next_event();
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse

@@ -3,6 +3,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "gemm_f64.h"
 
@@ -394,6 +395,21 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse) {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, greatest));
+        // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask enables CU i/8 of every XCD):
+        // the trailing updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.
+        if (n >= 2048 && !getenv("JAICOV_NO_CUMASK")) {
+            uint32_t upd[8], dia[8];
+            for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
+            upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u;
+            if (hipExtStreamCreateWithCUMask(&ustream, 8, upd) != hipSuccess) ustream = nullptr;
+            if (hipExtStreamCreateWithCUMask(&dstream, 8, dia) != hipSuccess) dstream = nullptr;
+            if (!ustream || !dstream) {
+                if (ustream) hipStreamDestroy(ustream);
+                if (dstream) hipStreamDestroy(dstream);
+                ustream = dstream = nullptr;
+                (void)hipGetLastError();
+            }
+        }
     }
     if (with_inverse) {
         HIPCHK(hipMalloc(&W, sq));
@@ -413,7 +429,9 @@ void DenseSolver::release() {
     for (auto ev : sync_ev) hipEventDestroy(ev);
     sync_ev.clear();
     if (pstream) hipStreamDestroy(pstream);
-    pstream = nullptr;
+    if (ustream) hipStreamDestroy(ustream);
+    if (dstream) hipStreamDestroy(dstream);
+    pstream = ustream = dstream = nullptr;
     L = invd = W = Q = T = nullptr;
     d_info = nullptr;
     owns = false;
@@ -426,7 +444,20 @@ void DenseSolver::release() {
 //   diagonal block factor + inverse (one workgroup, LDS)        L21 = A21 inv(L11)'  (GEMM with the inverse)
 // Lookahead: the trailing update of panel s is split into (a) the columns of panel s+1 and (b) the rest; panel s+1 is
 // factored on a second, high-priority stream as soon as (a) is done, while (b) keeps the chip busy.
+hipEvent_t DenseSolver::next_event() {
+    if (ev_used >= sync_ev.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        sync_ev.push_back(e);
+    }
+    return sync_ev[ev_used++];
+}
+
+// Panel factorisation of block columns [K0,K1).  GEMMs go to `st`; when a reserved-CU stream exists the diagonal-block
+// kernel (which needs a whole CU's LDS and would otherwise starve behind the trailing update's workgroups) runs there,
+// chained with events.
 hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
+    const bool split = dstream != nullptr && st == pstream;
     for (int k = K0; k < K1; k++) {
         double *Akk = L + (long)(k * 128) * ld + k * 128;
         const int rows_k = n - k * 128;
@@ -438,7 +469,19 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
             c.alpha = -1.0; c.beta = 1.0; c.lower_only = 0; c.kmode = KMODE_FULL;
             HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, c));
         }
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, Akk, ld, invd + (long)k * 16384, d_info, k, 0);
+        hipStream_t ds = st;
+        if (split) {
+            hipEvent_t e = next_event();
+            HIPCHK(hipEventRecord(e, st));
+            HIPCHK(hipStreamWaitEvent(dstream, e, 0));
+            ds = dstream;
+        }
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, ds, Akk, ld, invd + (long)k * 16384, d_info, k, 0);
+        if (split) {
+            hipEvent_t e = next_event();
+            HIPCHK(hipEventRecord(e, dstream));
+            HIPCHK(hipStreamWaitEvent(st, e, 0));
+        }
         const int rows = rows_k - 128;
         if (rows <= 0) break;
         double *A21 = L + (long)((k + 1) * 128) * ld + k * 128;
@@ -475,36 +518,40 @@ hipError_t DenseSolver::potrf() {
     const int S = (nb + bo - 1) / bo;
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
     const bool la = lookahead && pstream != nullptr && S > 1;
-    while ((int)sync_ev.size() < 2 * S + 2) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        sync_ev.push_back(e);
-    }
-    hipStream_t sp = la ? pstream : stream;
+    ev_used = 0;
+    hipStream_t sp = la ? pstream : stream;                 // panel GEMMs
+    hipStream_t su = la && ustream ? ustream : stream;      // trailing updates (all CUs but the reserved ones)
+    hipEvent_t e_start = next_event();
     if (la) {
-        HIPCHK(hipEventRecord(sync_ev[2 * S], stream));
-        HIPCHK(hipStreamWaitEvent(sp, sync_ev[2 * S], 0));
+        HIPCHK(hipEventRecord(e_start, stream));
+        HIPCHK(hipStreamWaitEvent(sp, e_start, 0));
+        if (su != stream) HIPCHK(hipStreamWaitEvent(su, e_start, 0));
     }
     HIPCHK(panel(sp, 0, bo < nb ? bo : nb));
-    if (la) HIPCHK(hipEventRecord(sync_ev[0], sp));
+    hipEvent_t e_panel = next_event();
+    if (la) HIPCHK(hipEventRecord(e_panel, sp));
     for (int s = 0; s < S; s++) {
         const int K0 = s * bo, K1 = (K0 + bo < nb) ? K0 + bo : nb;
         if (K1 >= nb) break;
         const int K2 = (K1 + bo < nb) ? K1 + bo : nb;     // end of the next panel
-        if (la) HIPCHK(hipStreamWaitEvent(stream, sync_ev[2 * s], 0));
+        if (la) HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
         const int Kw = (K1 - K0) * 128;
         // (a) columns of the next panel: rows >= K1, cols [K1,K2)
         GemmArgs a{};
         a.A = L + (long)(K1 * 128) * ld + K0 * 128; a.lda = ld; a.B = a.A; a.ldb = ld;
         a.C = L + (long)(K1 * 128) * ld + K1 * 128; a.ldc = ld;
         a.M = n - K1 * 128; a.N = (K2 - K1) * 128; a.K = Kw; a.alpha = -1.0; a.beta = 1.0; a.lower_only = 0; a.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(stream, LAY_KC, LAY_KC, a));
+        HIPCHK(gemm_f64(su, LAY_KC, LAY_KC, a));
         if (la) {
-            HIPCHK(hipEventRecord(sync_ev[2 * s + 1], stream));
-            HIPCHK(hipStreamWaitEvent(sp, sync_ev[2 * s + 1], 0));
+            hipEvent_t e = next_event();
+            HIPCHK(hipEventRecord(e, su));
+            HIPCHK(hipStreamWaitEvent(sp, e, 0));
         }
         HIPCHK(panel(sp, K1, K2));
-        if (la) HIPCHK(hipEventRecord(sync_ev[2 * (s + 1)], sp));
+        if (la) {
+            e_panel = next_event();
+            HIPCHK(hipEventRecord(e_panel, sp));
+        }
         // (b) the rest of the trailing matrix: rows, cols >= K2 (lower tiles)
         const int rows = n - K2 * 128;
         if (rows > 0) {
@@ -512,12 +559,17 @@ hipError_t DenseSolver::potrf() {
             u.A = L + (long)(K2 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
             u.C = L + (long)(K2 * 128) * ld + K2 * 128; u.ldc = ld;
             u.M = rows; u.N = rows; u.K = Kw; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
-            HIPCHK(timed_gemm(stream, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
+            HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
         }
     }
-    if (la) {   // the main stream continues only after the last panel
-        HIPCHK(hipEventRecord(sync_ev[2 * S + 1], sp));
-        HIPCHK(hipStreamWaitEvent(stream, sync_ev[2 * S + 1], 0));
+    if (la) {   // the main stream continues only after the last panel and the last update
+        hipEvent_t e1 = next_event(), e2 = next_event();
+        HIPCHK(hipEventRecord(e1, sp));
+        HIPCHK(hipStreamWaitEvent(stream, e1, 0));
+        if (su != stream) {
+            HIPCHK(hipEventRecord(e2, su));
+            HIPCHK(hipStreamWaitEvent(stream, e2, 0));
+        }
     }
     return hipGetLastError();
 }
@@ -640,6 +692,27 @@ hipError_t mfma_peak_bench(int blocks, int iters, float *ms_out, double *tflops)
     *tflops = (double)blocks * 4.0 * (iters < 0 ? -iters : iters) * 16.0 * 2048.0 / (*ms_out * 1e-3) / 1e12;
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(out);
+    return hipGetLastError();
+}
+
+// does hipExtStreamCreateWithCUMask work here?  runs the MFMA peak kernel on a stream restricted by `mask` (8 words)
+hipError_t cumask_bench(const uint32_t *mask, int blocks, int iters, float *ms_out, double *tflops) {
+    hipStream_t st;
+    HIPCHK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+    double *out = nullptr;
+    HIPCHK(hipMalloc(&out, 8));
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+    hipEventRecord(e0, st);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters);
+    hipEventRecord(e1, st);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(ms_out, e0, e1);
+    *tflops = (double)blocks * 4.0 * iters * 16.0 * 2048.0 / (*ms_out * 1e-3) / 1e12;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(out);
+    hipStreamDestroy(st);
     return hipGetLastError();
 }
 

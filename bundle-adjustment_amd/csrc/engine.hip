@@ -1062,6 +1062,13 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
 }
 
 namespace jaicov { hipError_t diag_kernel_bench(int dbg, int iters, float *ms_out); hipError_t mfma_peak_bench(int, int, float *, double *); }
+namespace jaicov { hipError_t cumask_bench(const uint32_t *, int, int, float *, double *); }
+extern "C" int jaicov_debug_cumask(const uint32_t *mask, int blocks, int iters, double *ms_out, double *tflops) {
+    float ms = 0;
+    hipError_t he = jaicov::cumask_bench(mask, blocks, iters, &ms, tflops);
+    *ms_out = ms;
+    return he == hipSuccess ? 0 : (int)he;
+}
 extern "C" int jaicov_debug_mfma_peak(int blocks, int iters, double *ms_out, double *tflops) {
     float ms = 0;
     hipError_t he = jaicov::mfma_peak_bench(blocks, iters, &ms, tflops);
