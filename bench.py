@@ -115,12 +115,10 @@ def main():
 
     def step():
         if use_dist:
-            eng.accumulate(s2)
-            distributed.allreduce_engine_buffer(eng, dist, torch.device("cuda", local))
-            eng.finalize(s2, 0.0)
+            dx = distributed.sharded_step(eng, dist, torch.device("cuda", local), s2)
         else:
             eng.build(s2, 0.0)
-        dx = eng.solve(False)
+            dx = eng.solve(False)
         eng.update(dx)
         return dx
 
@@ -179,12 +177,11 @@ def main():
         sync()
         t1 = time.perf_counter()
         if use_dist:
-            eng.accumulate(s2)
-            distributed.allreduce_engine_buffer(eng, dist, torch.device("cuda", local))
-            eng.finalize(s2, 0.0)
+            dx = distributed.sharded_step(eng, dist, torch.device("cuda", local), s2, invert=True)
         else:
+            eng.prepare_inverse(True)
             eng.build(s2, 0.0)
-        dx = eng.solve(True)
+            dx = eng.solve(True)
         om = eng.omega(s2, dx) if rank == 0 else 0.0
         sync()
         if rank == 0:

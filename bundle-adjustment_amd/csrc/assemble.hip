@@ -164,14 +164,17 @@ __global__ __launch_bounds__(128) void blk_T_kernel(DevProblem p, const int32_t 
 // B2: shared block S_cc = A_c' T_c, n_c = A_c' T_w  -> atomics (one workgroup per block)
 __global__ __launch_bounds__(256) void blk_cc_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
                                                      const double *__restrict__ rowsA, const double *__restrict__ T,
-                                                     double sigma2, double *__restrict__ N, double *__restrict__ n) {
+                                                     double sigma2, double *__restrict__ N, double *__restrict__ n,
+                                                     int schur) {
     __shared__ int cols[KC_MAX];
     const int g = blk_list[blockIdx.x];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
     const long S = p.n_ip;
     const int img = p.ip_image[ipb], cam = p.image_camera[img];
     const int jb = p.cam_dist_begin[cam], kc = 9 + p.cam_dist_begin[cam + 1] - jb;
-    if (threadIdx.x < kc) cols[threadIdx.x] = shared_col(p, img, cam, jb, threadIdx.x);
+    // schur: the EO columns (shared 3..8) are pre-eliminated (schur.hip) and do not enter the reduced system
+    if (threadIdx.x < kc)
+        cols[threadIdx.x] = (schur && threadIdx.x >= 3 && threadIdx.x < 9) ? -1 : shared_col(p, img, cam, jb, threadIdx.x);
     __syncthreads();
     const int nent = kc * (kc + 1);   // a in [0,kc), b in [0,kc] (b == kc -> n)
     for (int ent = threadIdx.x; ent < nent; ent += 256) {
@@ -194,10 +197,11 @@ __global__ __launch_bounds__(256) void blk_cc_kernel(DevProblem p, const int32_t
 __global__ __launch_bounds__(256) void blk_pc_kernel(DevProblem p, const int32_t *__restrict__ blk_of_ip,
                                                      const int32_t *__restrict__ ip_list, int n_list,
                                                      const double *__restrict__ rowsA, const double *__restrict__ T,
-                                                     double sigma2, double *__restrict__ N, double *__restrict__ n) {
+                                                     double sigma2, double *__restrict__ N, double *__restrict__ n,
+                                                     int schur) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const int li = (int)(gid / KC_LD), c = (int)(gid - (long)li * KC_LD);
-    if (li >= n_list) return;
+    if (li >= n_list || (schur && c >= 3 && c < 9)) return;
     const int ip = ip_list[li];
     (void)blk_of_ip;
     const long S = p.n_ip;
@@ -523,21 +527,35 @@ hipError_t launch_assemble_small(hipStream_t s, const DevProblem &p, const int32
     return hipGetLastError();
 }
 
+hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
+                                  const double *, const double *, double *, double, double, double *, double *, double *,
+                                  double *, int *, double *);
+
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
-                                  double *T, double sigma2, double *N, double *n, const PPGather &pp) {
+                                  double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb) {
     if (n_list <= 0) return hipSuccess;
+    const int schur = sb.Pp != nullptr;
     hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + 127) / 128, n_list), dim3(128), 0, s, p, blk_list, rowsA, rowsW, T);
-    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, T, sigma2, N, n);
+    DevProblem q = p;
+    double s2 = sigma2;
+    if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
+        hipError_t he = launch_schur_eliminate(s, p, blk_list, n_list, max_m, ip_list, n_ip_list, rowsA, rowsW, T, sigma2,
+                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.Pp, sb.info, sb.diagcorr);
+        if (he != hipSuccess) return he;
+        q.blk_w = sb.Pp;
+        s2 = 1.0;
+    }
+    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
     hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
-                       ip_list, n_ip_list, rowsA, T, sigma2, N, n);
+                       ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
     if (pp.pt_ip_begin) {
-        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(256), 0, s, p, pp.pt_ip_begin,
-                           pp.recs, pp.ipcol, rowsA, sigma2, N, pp.cmin);
+        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(256), 0, s, q, pp.pt_ip_begin,
+                           pp.recs, pp.ipcol, rowsA, s2, N, pp.cmin);
     } else {
         const int mp = max_m / 2;
-        hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, p, blk_list, rowsA, sigma2, N);
+        hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, q, blk_list, rowsA, s2, N);
     }
     return hipGetLastError();
 }

@@ -15,6 +15,7 @@ constexpr int KROW = 12 + MAXD;                    // local row layout: X,Y,Z,x0
 constexpr int KC_MAX = 9 + MAXD;                   // shared (camera + EO) local columns: io(3), eo(6), dist
 constexpr int KC_LD = KC_MAX + 1;                  // + the misclosure column in T = P [A_c | w]
 constexpr int SEG = 256;                           // image points per assembly segment
+constexpr int SCHUR_GLD = 24;                      // row length of G = U' [A_io, A_dist | w] (schur.hip)
 
 // Device-side view of jaicov_problem_desc (device pointers) + derived tables
 struct DevProblem {
@@ -47,6 +48,13 @@ struct PPGather {
     const PPRecord *recs = nullptr;         // image order within a point
     const int32_t *ipcol = nullptr;         // [3*n_ip] column of X,Y,Z of the point seen by image point ip
     int cmin = 0, n_chunks = 0;
+};
+
+// buffers of the per-image EO pre-elimination (schur.hip); Pp == nullptr -> mode off
+struct SchurBufs {
+    double *U = nullptr, *Linv = nullptr, *G = nullptr, *Pp = nullptr, *diagcorr = nullptr;
+    int *info = nullptr;
+    double lambda = 0.0;
 };
 
 // ---- slot layout ------------------------------------------------------------------------------------------------

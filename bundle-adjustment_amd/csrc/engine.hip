@@ -22,7 +22,10 @@ hipError_t launch_rows(hipStream_t, const DevProblem &, const double *, int, int
 hipError_t launch_assemble_small(hipStream_t, const DevProblem &, const int32_t *, const int32_t *, int, const double *,
                                  const double *, double, double *, double *);
 hipError_t launch_assemble_blocks(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
-                                  const double *, const double *, double *, double, double *, double *, const PPGather &);
+                                  const double *, const double *, double *, double, double *, double *, const PPGather &,
+                                  const SchurBufs &);
+hipError_t launch_schur_backsub(hipStream_t, const DevProblem &, const int32_t *, int, const double *, const double *,
+                                const double *, double *);
 hipError_t launch_shared_groups(hipStream_t, const DevProblem &, const double *, double, double *, double *,
                                 const double *, double *);
 hipError_t launch_omega(hipStream_t, const DevProblem &, const uint8_t *, int, int, const int32_t *, int, int,
@@ -38,14 +41,16 @@ static const double EPS53 = 1.1102230246251565e-16;   // Constant.EPS = 2^-53 (C
 // ---------------------------------------------------------------------------------------------------------------
 // BA:814-828: damping on unknown columns, then V = 1/sqrt(diag) where diag > EPS (V = 1 on the border, whose
 // diagonal is zero); padded rows get V = 1
-__global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int d, double lambda, double *V) {
+__global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int d, double lambda, double *V,
+                                        const double *diagcorr) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= Upad) return;
     double v = 1.0;
     if (c >= d && c < U) {
         double diag = N[(long)c * ld + c];
         if (lambda > 0.0) {
-            diag += lambda * diag;
+            // the reference damps the diagonal of the UNREDUCED normal matrix; diagcorr = what the EO elimination took
+            diag += lambda * (diag + (diagcorr ? diagcorr[c] : 0.0));
             N[(long)c * ld + c] = diag;
         }
         v = diag > 1.1102230246251565e-16 ? 1.0 / sqrt(diag) : 1.0;
@@ -53,18 +58,18 @@ __global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int
     V[c] = v;
 }
 
-// M = V N V + Bh' Bh on the unknown block (lower part), identity on border and padding.  Bh: [d][Upad]
-__global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restrict__ N, double *__restrict__ M, long ld,
-                                                         int U, int Upad, int d, const double *__restrict__ V,
-                                                         const double *__restrict__ Bh) {
+// M = V N V + Bh' Bh on the unknown block (lower part), identity on border and padding.  Bh: [d][bstride]
+__global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restrict__ N, long ldN, double *__restrict__ M,
+                                                         long ld, int U, int Upad, int d, const double *__restrict__ V,
+                                                         const double *__restrict__ Bh, int bstride) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
     if (j > i || j >= Upad) return;
     double v;
     if (i < d || i >= U || j < d) v = (i == j) ? 1.0 : 0.0;
     else {
-        v = V[i] * N[(long)i * ld + j] * V[j];
-        for (int a = 0; a < d; a++) v += Bh[(long)a * Upad + i] * Bh[(long)a * Upad + j];
+        v = V[i] * N[(long)i * ldN + j] * V[j];
+        for (int a = 0; a < d; a++) v += Bh[(long)a * bstride + i] * Bh[(long)a * bstride + j];
     }
     M[(long)i * ld + j] = v;
 }
@@ -153,6 +158,15 @@ struct jaicov_engine {
     int32_t *d_seg_begin = nullptr, *d_seg_end = nullptr, *d_blk_list = nullptr, *d_blk_ip_list = nullptr;
     uint8_t *d_in_block = nullptr;
     PPGather pp;
+    // EO pre-elimination (schur.hip)
+    bool schur_ok = false, schur_active = false, want_inverse_next = false;
+    std::vector<int> h_blk_images;   // image of every block handled by this engine
+    int e0 = 0;                   // first EO column == order of the reduced system
+    SchurBufs sb;
+    double *d_xE = nullptr;
+    DenseSolver solverS;
+    bool solverS_ready = false;
+    double lambda_acc = 0.0;
     // device state
     double *d_vals = nullptr, *d_rowsA = nullptr, *d_rowsW = nullptr, *d_T = nullptr, *d_vbuf = nullptr;
     double *d_N = nullptr, *d_n = nullptr;          // one allocation: N (Upad x Upad) followed by n (Upad)
@@ -239,6 +253,7 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     hipSetDevice(e->device);
     if (e->stream) hipStreamSynchronize(e->stream);
     e->solver.release();
+    e->solverS.release();
     for (void *ptr : e->allocs) hipFree(ptr);
     for (auto &evt : e->ev)
         if (evt) hipEventDestroy(evt);
@@ -302,7 +317,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
     std::vector<uint8_t> in_block(D->n_image_points + 1, 0);
     std::vector<int32_t> blk_list, blk_ip_list, seg_b, seg_e;
     std::vector<int64_t> blk_w_off(D->n_image_blocks + 1, 0);
-    int64_t w_total = 0;
+    int64_t w_total = 0, w_total_saved = 0;
     for (int g = 0; g < D->n_image_blocks; g++) {
         const int b = D->blk_ip_begin[g], en = D->blk_ip_begin[g + 1];
         if (en < b || b < 0 || en > D->n_image_points) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "image blocks must be ascending ranges");
@@ -327,6 +342,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
         seg_b.push_back(ip); seg_e.push_back(en);
         ip = en;
     }
+    w_total_saved = w_total;
+    for (int g : blk_list) e->h_blk_images.push_back(D->ip_image[D->blk_ip_begin[g]]);
     e->n_seg = (int)seg_b.size();
     e->n_blk_list = (int)blk_list.size();
     e->n_blk_ip = (int)blk_ip_list.size();
@@ -479,6 +496,29 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
     if ((rc = dalloc(e, (size_t)64, &e->d_E, true))) return rc;
     if ((rc = dalloc(e, (size_t)1, &e->d_omega, true))) return rc;
     HIPE(e, e->solver.init(e->stream, e->Upad, false));
+    // ---- EO pre-elimination is possible when every image point sits in an image block, the EO columns are the
+    //      trailing columns e0 + 6*image + k, and no directly observed parameter is an EO parameter ------------------
+    {
+        const char *env = getenv("JAICOV_SCHUR");
+        bool ok = !(env && env[0] == '0') && D->n_images > 0 && D->n_image_blocks > 0 && e->n_seg == 0 && e->n_blk_ip == e->ip_count;
+        const int e0 = D->n_images > 0 ? D->eo_col[0] : -1;
+        ok = ok && e0 >= d && e0 + 6 * D->n_images == U;
+        for (int i = 0; ok && i < 6 * D->n_images; i++) ok = D->eo_col[i] == e0 + i;
+        const int s_eo = 3 * D->n_points + 3 * D->n_cameras + D->n_dist;
+        for (int r = 0; ok && r < D->n_direct_rows; r++) ok = D->dg_slot[r] < s_eo;
+        for (int g = 0; ok && g < D->n_image_blocks; g++) ok = D->blk_ip_begin[g + 1] - D->blk_ip_begin[g] >= 3;
+        if (ok) {
+            if ((rc = dalloc(e, (size_t)16 * std::max(1, D->n_image_points), &e->sb.U, true))) return rc;
+            if ((rc = dalloc(e, (size_t)36 * D->n_images, &e->sb.Linv, true))) return rc;
+            if ((rc = dalloc(e, (size_t)6 * SCHUR_GLD * D->n_images, &e->sb.G, true))) return rc;
+            if ((rc = dalloc(e, (size_t)std::max<int64_t>(w_total_saved, 1), &e->sb.Pp))) return rc;
+            if ((rc = dalloc(e, (size_t)6 * D->n_images, &e->d_xE, true))) return rc;
+            if ((rc = dalloc(e, (size_t)1, &e->sb.info, true))) return rc;
+            if ((rc = dalloc(e, (size_t)e->Upad, &e->sb.diagcorr, true))) return rc;
+            e->schur_ok = true;
+            e->e0 = e0;
+        }
+    }
     e->h_vals.assign(e->n_slots, 0.0);
     e->h_V.assign(e->Upad, 1.0);
     e->hB.assign((size_t)8 * e->Upad, 0.0);
@@ -546,8 +586,16 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     HIPE(e, hipEventRecord(e->ev[1], e->stream));
     HIPE(e, hipMemsetAsync(e->d_N, 0, (sq + e->Upad) * sizeof(double), e->stream));
     HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
+    e->schur_active = e->schur_ok && !e->want_inverse_next;
+    SchurBufs sb = e->sb;
+    if (!e->schur_active) sb.Pp = nullptr;
+    sb.lambda = e->lambda_acc;
+    if (e->schur_active) {
+        HIPE(e, hipMemsetAsync(e->sb.info, 0, sizeof(int), e->stream));
+        HIPE(e, hipMemsetAsync(e->sb.diagcorr, 0, (size_t)e->Upad * sizeof(double), e->stream));
+    }
     HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
-                                   e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, e->pp));
+                                   e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, e->pp, sb));
     if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, e->d_N, e->d_n, nullptr, nullptr));
     HIPE(e, hipEventRecord(e->ev[2], e->stream));
     e->state = jaicov_engine::ST_ACCUMULATED;
@@ -605,13 +653,17 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
     int rc = datum_rows_host(e);
     if (rc) return rc;
     if (e->reduced) {   // the host has summed the packed buffer over ranks: bring it back into the square
-        const size_t len = (size_t)e->U * (e->U + 1) / 2;
-        hipLaunchKernelGGL(unpack_kernel, dim3((e->U + 255) / 256, std::max(e->U, 1)), dim3(256), 0, e->stream, e->d_packed, (long)e->Upad, e->U, e->d_N);
-        HIPE(e, hipMemcpyAsync(e->d_n, e->d_packed + len, (size_t)e->U * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        const int Ua = e->schur_active ? e->e0 : e->U;
+        const size_t len = (size_t)Ua * (Ua + 1) / 2;
+        hipLaunchKernelGGL(unpack_kernel, dim3((Ua + 255) / 256, std::max(Ua, 1)), dim3(256), 0, e->stream, e->d_packed, (long)e->Upad, Ua, e->d_N);
+        HIPE(e, hipMemcpyAsync(e->d_n, e->d_packed + len, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         e->reduced = false;
     }
+    if (e->schur_active && lambda != e->lambda_acc && (lambda > 0 || e->lambda_acc > 0))
+        FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "EO pre-elimination: pass the damping value to accumulate2()/build() as well");
     hipLaunchKernelGGL(damp_and_precond_kernel, dim3((e->Upad + 255) / 256), dim3(256), 0, e->stream, e->d_N, (long)e->Upad,
-                       e->U, e->Upad, e->d, lambda > 0 ? lambda : 0.0, e->d_V);
+                       e->schur_active ? e->e0 : e->U, e->Upad, e->d, lambda > 0 ? lambda : 0.0, e->d_V,
+                       e->schur_active ? e->sb.diagcorr : nullptr);
     if (simulation) HIPE(e, hipMemsetAsync(e->d_n, 0, e->Upad * sizeof(double), e->stream));   // BA:830-831
     HIPE(e, hipEventRecord(e->ev[3], e->stream));
     e->lambda_used = lambda;
@@ -619,7 +671,26 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
     return JAICOV_OK;
 }
 
+extern "C" int jaicov_neq_prepare_inverse(jaicov_engine *e, int inverse_follows) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    e->want_inverse_next = inverse_follows != 0;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_reduced_order(const jaicov_engine *e) {
+    if (!e) return -1;
+    return e->schur_active ? e->e0 : e->U;
+}
+
+extern "C" int jaicov_neq_accumulate2(jaicov_engine *e, double sigma2, double lambda) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    e->lambda_acc = lambda > 0 ? lambda : 0.0;
+    return jaicov_neq_accumulate(e, sigma2);
+}
+
 extern "C" int jaicov_neq_build(jaicov_engine *e, double sigma2, double lambda, int simulation) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    e->lambda_acc = lambda > 0 ? lambda : 0.0;
     int rc = jaicov_neq_accumulate(e, sigma2);
     if (rc) return rc;
     return jaicov_neq_finalize(e, sigma2, lambda, simulation);
@@ -629,18 +700,20 @@ extern "C" int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, siz
     if (!e || !device_ptr || !count) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state != jaicov_engine::ST_ACCUMULATED) FAIL(e, JAICOV_ERR_BAD_STATE, "accumulate first");
     HIPE(e, hipSetDevice(e->device));
-    // packed lower triangle (== UPLO='U' packed) followed by n: one contiguous array the collective sums as it is
-    const size_t len = (size_t)e->U * (e->U + 1) / 2;
+    // packed lower triangle (== UPLO='U' packed) followed by n: one contiguous array the collective sums as it is.
+    // With the EO pre-elimination only the reduced system (order e0) exists.
+    const int Ua = e->schur_active ? e->e0 : e->U;
+    const size_t len = (size_t)Ua * (Ua + 1) / 2;
     if (!e->d_packed) {
-        int rc = dalloc(e, len + e->U, &e->d_packed);
+        int rc = dalloc(e, (size_t)e->U * (e->U + 1) / 2 + e->U, &e->d_packed);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(pack_kernel, dim3((e->U + 255) / 256, std::max(e->U, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, e->U, e->d_packed);
-    HIPE(e, hipMemcpyAsync(e->d_packed + len, e->d_n, (size_t)e->U * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    hipLaunchKernelGGL(pack_kernel, dim3((Ua + 255) / 256, std::max(Ua, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, Ua, e->d_packed);
+    HIPE(e, hipMemcpyAsync(e->d_packed + len, e->d_n, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     HIPE(e, hipStreamSynchronize(e->stream));   // the caller's collective runs on its own stream
     e->reduced = true;
     *device_ptr = e->d_packed;
-    *count = len + e->U;
+    *count = len + Ua;
     return JAICOV_OK;
 }
 
@@ -674,8 +747,27 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     if (!e || !dx_out) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state != jaicov_engine::ST_BUILT) FAIL(e, JAICOV_ERR_BAD_STATE, "build first");
     HIPE(e, hipSetDevice(e->device));
-    const int U = e->U, Upad = e->Upad, d = e->d, nrhs = d + 1;
-    const long ld = Upad;
+    const bool schur = e->schur_active;
+    if (schur && invert)
+        FAIL(e, JAICOV_ERR_BAD_STATE, "the normal equations were assembled with the EO blocks pre-eliminated: call "
+                                      "jaicov_neq_prepare_inverse(e, 1) before the build whose solve shall invert");
+    // order of the system that is factorised: the reduced one (points, IO, distortion) or the full one
+    const int U = schur ? e->e0 : e->U, d = e->d, nrhs = d + 1;
+    const int Upad = e->Upad;                      // leading dimension of N, V, B and the rhs/solution vectors
+    if (schur && !e->solverS_ready) {
+        HIPE(e, e->solverS.init(e->stream, ((e->e0 + 127) / 128) * 128, false));
+        e->solverS_ready = true;
+    }
+    DenseSolver &slv = schur ? e->solverS : e->solver;
+    slv.profile = e->solver.profile;
+    const int Up = slv.n;                          // padded order of the factorised system
+    const long ld = slv.ld;
+    if (schur) {
+        int hinfo = 0;
+        HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
+    }
     if (invert && !e->solver_has_inverse) {
         const size_t sq = (size_t)Upad * Upad * sizeof(double);
         HIPE(e, hipMalloc(&e->solver.W, sq));
@@ -703,29 +795,32 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     if (d > 0) HIPE(e, hipMemcpyAsync(e->d_B, Bh.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPE(e, hipEventRecord(e->ev[4], e->stream));
-    hipLaunchKernelGGL(scale_copy_kernel, dim3((Upad + 255) / 256, Upad), dim3(256), 0, e->stream, e->d_N, e->solver.L, ld, U,
-                       Upad, d, e->d_V, e->d_B);
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((Up + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
+                       Up, d, e->d_V, e->d_B, Upad);
     // right-hand sides: row 0 = V n, rows 1..d = Bh
-    hipLaunchKernelGGL(scale_vec_kernel, dim3((Upad + 255) / 256), dim3(256), 0, e->stream, e->d_n, e->d_V, e->d_Y, U, Upad, d);
-    if (d > 0) HIPE(e, hipMemcpyAsync(e->d_Y + Upad, e->d_B, (size_t)d * Upad * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    HIPE(e, e->solver.potrf());
+    const int vs = Up;   // stride between the rhs / solution vectors (the solver's order)
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((Up + 255) / 256), dim3(256), 0, e->stream, e->d_n, e->d_V, e->d_Y, U, Up, d);
+    if (d > 0)
+        HIPE(e, hipMemcpy2DAsync(e->d_Y + vs, (size_t)vs * sizeof(double), e->d_B, (size_t)Upad * sizeof(double),
+                                 (size_t)Up * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, e->stream));
+    HIPE(e, slv.potrf());
     HIPE(e, hipEventRecord(e->ev[5], e->stream));
-    HIPE(e, hipMemcpyAsync(e->d_Yw, e->d_Y, (size_t)nrhs * Upad * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    HIPE(e, e->solver.forwardsolve(e->d_Yw, e->d_X, nrhs));       // X <- L^-1 Y
-    HIPE(e, e->solver.backsolve(e->d_X, e->d_Yw, e->d_G, nrhs));  // G <- L^-T X   (row 0: y~, rows 1..d: G^)
+    HIPE(e, hipMemcpyAsync(e->d_Yw, e->d_Y, (size_t)nrhs * vs * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPE(e, slv.forwardsolve(e->d_Yw, e->d_X, nrhs));       // X <- L^-1 Y
+    HIPE(e, slv.backsolve(e->d_X, e->d_Yw, e->d_G, nrhs));  // G <- L^-T X   (row 0: y~, rows 1..d: G^)
     HIPE(e, hipEventRecord(e->ev[6], e->stream));
-    std::vector<double> X((size_t)nrhs * Upad);
+    std::vector<double> X((size_t)nrhs * vs);
     HIPE(e, hipMemcpyAsync(X.data(), e->d_G, X.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    const int info = e->solver.fetch_info();
+    const int info = slv.fetch_info();
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "normal-equation matrix is singular / not positive definite at pivot " + std::to_string(info));
     // ---- rank-d border algebra on the host ---------------------------------------------------------------------
     double Sm[49], Sinv[49], kh[7];
-    std::vector<double> y(X.begin(), X.begin() + Upad);
+    std::vector<double> y(X.begin(), X.begin() + vs);
     if (d > 0) {
         for (int a = 0; a < d; a++)
             for (int b = 0; b < d; b++) {
                 double s = 0.0;
-                for (int c = d; c < U; c++) s += Bh[(size_t)a * Upad + c] * X[(size_t)(1 + b) * Upad + c];
+                for (int c = d; c < U; c++) s += Bh[(size_t)a * Upad + c] * X[(size_t)(1 + b) * vs + c];
                 Sm[a * d + b] = s;
             }
         if (!small_inverse(d, Sm, Sinv)) FAIL(e, JAICOV_ERR_SINGULAR, "datum conditions are linearly dependent");
@@ -742,13 +837,29 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         }
         for (int c = d; c < U; c++) {
             double s = 0.0;
-            for (int a = 0; a < d; a++) s += X[(size_t)(1 + a) * Upad + c] * kh[a];
+            for (int a = 0; a < d; a++) s += X[(size_t)(1 + a) * vs + c] * kh[a];
             y[c] -= s;
         }
     }
     for (int c = 0; c < U; c++) dx_out[c] = c < d ? R[c] * kh[c] : e->h_V[c] * y[c];
     for (int c = 0; c < U; c++)
         if (!std::isfinite(dx_out[c])) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite step");
+    if (schur) {
+        // EO step of every image of this engine: dx_E = L_E^-T U' (w - A_r dx_R)   (schur.hip)
+        for (int c = U; c < e->U; c++) dx_out[c] = 0.0;
+        HIPE(e, hipMemcpyAsync(e->d_dx, dx_out, (size_t)e->U * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPE(e, launch_omega(e->stream, e->p, e->d_in_block, e->ip0, e->ip_count, e->d_blk_list, 0, e->max_m, e->d_rowsA,
+                             e->d_rowsW, e->d_dx, 1.0, e->d_vbuf, e->d_omega));
+        HIPE(e, launch_schur_backsub(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->sb.U, e->sb.Linv, e->d_vbuf, e->d_xE));
+        std::vector<double> xE((size_t)6 * e->p.n_images);
+        HIPE(e, hipMemcpyAsync(xE.data(), e->d_xE, xE.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        for (int img : e->h_blk_images)
+            for (int k = 0; k < 6; k++) {
+                dx_out[e->e0 + 6 * img + k] = xE[(size_t)6 * img + k];
+                if (!std::isfinite(xE[(size_t)6 * img + k])) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite step");
+            }
+    }
     if (invert) {
         HIPE(e, e->solver.trtri());
         HIPE(e, e->solver.lauum());
@@ -758,7 +869,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         for (int a = 0; a < d; a++) {
             for (int c = d; c < U; c++) {
                 double s = 0.0;
-                for (int b = 0; b < d; b++) s += Sinv[a * d + b] * X[(size_t)(1 + b) * Upad + c];
+                for (int b = 0; b < d; b++) s += Sinv[a * d + b] * X[(size_t)(1 + b) * vs + c];
                 H[(size_t)a * Upad + c] = s;
                 F[(size_t)a * Upad + c] = R[a] * s * e->h_V[c];
             }
@@ -778,7 +889,11 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
     }
-    e->solver.prof_collect();
+    slv.prof_collect();
+    if (schur) {
+        e->solver.stat_launches += slv.stat_launches; e->solver.stat_ms += slv.stat_ms; e->solver.stat_flops += slv.stat_flops;
+        slv.stat_launches = slv.stat_ms = slv.stat_flops = 0.0;
+    }
     float ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[1]); e->timings[0] = ms;
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timings[1] = ms;
@@ -952,6 +1067,7 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
         maxAbsDx = 0.0;
         iter = max_iter - runs;
         if (deriveFirst) { adapted = damping; deriveFirst = false; }
+        jaicov_neq_prepare_inverse(e, isEstimated && o->invert);
         rc = jaicov_neq_build(e, sigma2, adapted, o->simulation);
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
         if (rc) { state = rc == JAICOV_ERR_BAD_ARGUMENT || rc > 0 ? -2 : -1; break; }

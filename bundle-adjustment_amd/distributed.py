@@ -58,8 +58,19 @@ def allreduce_engine_buffer(eng, dist, device):
 
 
 def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
-    """One pass of the loop body on a sharded engine: accumulate -> all-reduce -> finalize -> solve."""
-    eng.accumulate(sigma2)
+    """One pass of the loop body on a sharded engine: accumulate -> all-reduce -> finalize -> solve.
+
+    When the engine pre-eliminates the exterior-orientation blocks, every rank's dx carries only its own images' EO
+    entries (the rest is zero): they are summed over the ranks (6 doubles per image)."""
+    import torch
+    eng.prepare_inverse(invert)
+    eng.accumulate(sigma2, lam)
     allreduce_engine_buffer(eng, dist, device)
     eng.finalize(sigma2, lam)
-    return eng.solve(invert)
+    dx = eng.solve(invert)
+    e0 = eng.reduced_order()
+    if e0 < eng.U and dist.get_world_size() > 1:
+        t = torch.from_numpy(dx[e0:].copy()).to(device)
+        dist.all_reduce(t)
+        dx[e0:] = t.cpu().numpy()
+    return dx

@@ -22,7 +22,8 @@ STATUS = {0: "OK", -1: "BAD_ARGUMENT", -2: "BAD_STATE", -3: "UNSUPPORTED", -4: "
 EXPORTS = [
     "jaicov_neq_create", "jaicov_neq_destroy", "jaicov_neq_last_error", "jaicov_neq_abi_version",
     "jaicov_neq_num_slots", "jaicov_neq_packed_length", "jaicov_neq_set_parameters", "jaicov_neq_get_parameters",
-    "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_finalize", "jaicov_neq_reduce_buffer",
+    "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_accumulate2", "jaicov_neq_prepare_inverse", "jaicov_neq_reduced_order",
+    "jaicov_neq_finalize", "jaicov_neq_reduce_buffer",
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
     "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats",
@@ -90,6 +91,9 @@ def load_library():
     L.jaicov_neq_get_parameters.argtypes = [vp, _pd, C.c_size_t]
     L.jaicov_neq_build.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.jaicov_neq_accumulate.argtypes = [vp, C.c_double]
+    L.jaicov_neq_accumulate2.argtypes = [vp, C.c_double, C.c_double]
+    L.jaicov_neq_prepare_inverse.argtypes = [vp, C.c_int]
+    L.jaicov_neq_reduced_order.argtypes = [vp]
     L.jaicov_neq_finalize.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.jaicov_neq_reduce_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.jaicov_neq_solve.argtypes = [vp, C.c_int, _pd]
@@ -165,8 +169,16 @@ class Engine:
     def build(self, sigma2, lam=0.0, simulation=False):
         self._chk(self.L.jaicov_neq_build(self._h, sigma2, lam, int(simulation)))
 
-    def accumulate(self, sigma2):
-        self._chk(self.L.jaicov_neq_accumulate(self._h, sigma2))
+    def accumulate(self, sigma2, lam=0.0):
+        self._chk(self.L.jaicov_neq_accumulate2(self._h, sigma2, lam))
+
+    def reduced_order(self):
+        """Order of the system assembled by the last accumulate (U, or the first EO column with EO pre-elimination)."""
+        return int(self.L.jaicov_neq_reduced_order(self._h))
+
+    def prepare_inverse(self, inverse_follows=True):
+        """Tell the engine that the solve after the next build inverts (final pass): it then assembles the full system."""
+        self._chk(self.L.jaicov_neq_prepare_inverse(self._h, int(inverse_follows)))
 
     def finalize(self, sigma2, lam=0.0, simulation=False):
         self._chk(self.L.jaicov_neq_finalize(self._h, sigma2, lam, int(simulation)))

@@ -358,6 +358,7 @@ EstimationStateType BundleAdjustment::estimateModel() {
         iterationStep_ = maxIter_ - runs;
         fire("ITERATE", maxIter_, iterationStep_);
         if (deriveFirst) { adapted = damping_; deriveFirst = false; }                         // BA:801-812
+        jaicov_neq_prepare_inverse(engine_, isEstimated && wantInverse ? 1 : 0);   // BA:250: the final pass is known before it is built
         if ((rc = jaicov_neq_build(engine_, sigma2apriori_, adapted, simulation ? 1 : 0)) != JAICOV_OK) return fail(rc);   // BA:235
         if (interrupt_) { interrupt_ = false; return EstimationStateType::INTERRUPT; }         // BA:240-245
         complete = isEstimated;

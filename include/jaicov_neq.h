@@ -169,6 +169,16 @@ int jaicov_neq_get_parameters(jaicov_engine *e, double *slots, size_t n_slots);
  * = accumulate + (host all-reduce for multi-GPU) + finalize.                                             */
 int jaicov_neq_build(jaicov_engine *e, double sigma2apriori, double lambda, int simulation);
 int jaicov_neq_accumulate(jaicov_engine *e, double sigma2apriori);
+/* accumulate with the LM damping value known up front (needed when the engine pre-eliminates the exterior-orientation
+ * blocks per image while assembling, the device-side form of MatrixInversion.PRE_ELIMINATION, BA:283-291,1197-1453). */
+int jaicov_neq_accumulate2(jaicov_engine *e, double sigma2apriori, double lambda);
+/* Announces that the solve after the NEXT build will be called with invert != 0 (the final pass, BA:252-280): that
+ * build then assembles the full system instead of the EO-reduced one.  estimateModel knows this before it builds
+ * (BA:250 estimateCompleteModel = isEstimated).                                                                     */
+int jaicov_neq_prepare_inverse(jaicov_engine *e, int inverse_follows);
+/* Order of the system the last accumulate assembled: U, or the first EO column when the EO blocks were pre-eliminated
+ * (then every rank's solve returns dx with only ITS images' EO entries filled; a multi-GPU host sums dx[order..U)).   */
+int jaicov_neq_reduced_order(const jaicov_engine *e);
 int jaicov_neq_finalize(jaicov_engine *e, double sigma2apriori, double lambda, int simulation);
 
 /* Device buffer holding this rank's partial normal equations between accumulate and finalize: one contiguous

@@ -18,7 +18,7 @@ for name in names:
         tm = eng.timings()
         print(f"  it{it} wall={wall*1e3:.1f}ms max|dx|={mx:.3e} " + " ".join(f"{k}={v:.2f}" for k, v in tm.items()), flush=True)
     t = time.time()
-    eng.build(s2, 0.0); dx = eng.solve(True); om = eng.omega(s2, dx)
+    eng.prepare_inverse(True); eng.build(s2, 0.0); dx = eng.solve(True); om = eng.omega(s2, dx)
     wall = time.time() - t
     tm = eng.timings()
     print(f"  final(invert) wall={wall*1e3:.1f}ms omega={om:.4e} s0ratio={om/fp.degree_of_freedom/s2:.3f} " + " ".join(f"{k}={v:.2f}" for k, v in tm.items()), flush=True)

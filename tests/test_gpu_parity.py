@@ -93,6 +93,7 @@ def test_normal_equations_match_oracle(oracle_mod, name):
         No, no, Vo = o.build(fp.values, s2, lam)
         eng = engine.Engine(fp)
         eng.set_parameters(fp.values)
+        eng.prepare_inverse(True)          # full system (no EO pre-elimination), as the reference assembles it
         eng.build(s2, lam)
         N, n = eng.get_normal()
         U = fp.n_unknowns
@@ -112,6 +113,7 @@ def test_solve_matches_oracle(oracle_mod, name, invert):
     dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, invert)
     eng = engine.Engine(fp)
     eng.set_parameters(fp.values)
+    eng.prepare_inverse(invert)
     eng.build(s2, 0.0)
     dx = eng.solve(invert)
     d = fp.rank_defect
@@ -164,12 +166,12 @@ def test_estimate_lm_and_simulation(oracle_mod):
 def test_sharded_engines_sum_to_full(oracle_mod):
     fp = scene.config("tiny_block")
     s2 = fp.sigma2apriori
-    full = engine.Engine(fp); full.set_parameters(fp.values); full.build(s2); N, n = full.get_normal()
+    full = engine.Engine(fp); full.set_parameters(fp.values); full.prepare_inverse(True); full.build(s2); N, n = full.get_normal()
     h = fp.n_images // 2
     a = engine.Engine(fp, image_range=(0, h), apply_shared=True)
     b = engine.Engine(fp, image_range=(h, fp.n_images), apply_shared=False)
     for e_ in (a, b):
-        e_.set_parameters(fp.values); e_.accumulate(s2)
+        e_.set_parameters(fp.values); e_.prepare_inverse(True); e_.accumulate(s2)
     Na, na = a.get_normal(); Nb, nb = b.get_normal()
     np.testing.assert_allclose(Na + Nb, N, rtol=1e-12, atol=1e-13 * np.abs(N).max())
     np.testing.assert_allclose(na + nb, n, rtol=1e-12, atol=1e-13 * np.abs(n).max())
@@ -214,3 +216,47 @@ def test_rccl_reduce_path_world1(oracle_mod):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_eo_pre_elimination_matches_full_solve(oracle_mod, lam):
+    """schur.hip: eliminating the exterior-orientation blocks per image (rank-6 downdate of each image's weight matrix)
+    must give the same step as the reference's full bordered solve -- reduced order, identical dx incl. the EO part."""
+    fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    dxo, _, _, _ = o.step(fp.values, s2, lam, False)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.build(s2, lam)
+    assert eng.reduced_order() == fp.n_unknowns - 6 * fp.n_images      # the EO columns are gone from the system
+    dx = eng.solve(False)
+    np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    assert abs(eng.omega(s2, dx) - o.omega(fp.values, s2, dxo)) <= 1e-9 * o.omega(fp.values, s2, dxo)
+    with pytest.raises(engine.EngineError):
+        eng.build(s2, lam); eng.solve(True)          # inverse needs the full system: prepare_inverse first
+    eng.prepare_inverse(True); eng.build(s2, lam)
+    assert eng.reduced_order() == fp.n_unknowns
+    np.testing.assert_allclose(eng.solve(True), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    eng.close()
+
+
+def test_eo_pre_elimination_sharded(oracle_mod):
+    """Two engines over disjoint image ranges: reduced systems add up, each returns its own images' EO step."""
+    fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    s2 = fp.sigma2apriori
+    dxo, _, _, _ = oracle_mod.Oracle(fp).step(fp.values, s2, 0.0, False)
+    full = engine.Engine(fp); full.set_parameters(fp.values); full.build(s2); N, n = full.get_normal()
+    e0 = full.reduced_order()
+    a = engine.Engine(fp, image_range=(0, 3), apply_shared=True)
+    b = engine.Engine(fp, image_range=(3, fp.n_images), apply_shared=False)
+    for e_ in (a, b):
+        e_.set_parameters(fp.values); e_.accumulate(s2)
+    Na, na = a.get_normal(); Nb, nb = b.get_normal()
+    np.testing.assert_allclose(Na + Nb, N, rtol=1e-11, atol=1e-12 * np.abs(N).max())
+    np.testing.assert_allclose(na + nb, n, rtol=1e-11, atol=1e-12 * np.abs(n).max())
+    dx = full.solve(False)
+    np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    assert np.all(dx[e0:] != 0)
+    for e_ in (full, a, b):
+        e_.close()
