@@ -263,11 +263,13 @@ __global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t
 // The walk is software-pipelined: the loads of image o+1 (one 32-byte record, then Dinv rows / columns / Jacobian rows
 // of up to 512 points, two per thread) are in flight while image o is accumulated.
 constexpr int PP_CW = 4992;
+constexpr int PP_NT = 512;       // threads per workgroup of the gather
+constexpr int PP_Q = 1;          // points per thread and pass (PP_NT * PP_Q points of an image per pass)
 
-struct PPData {           // what one thread needs of one image: two points q = tid, tid + 256
-    d2_t P0[2], P1[2];
-    double aq[2][6];
-    int cq[2][3];
+struct PPData {           // what one thread needs of one image: PP_Q points q = tid + PP_NT * i
+    d2_t P0[PP_Q], P1[PP_Q];
+    double aq[PP_Q][6];
+    int cq[PP_Q][3];
     double ap0[3], ap1[3];
 };
 
@@ -283,8 +285,8 @@ __device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PP
         d.ap1[a] = sigma2 * rowsA[(long)(2 * a + 1) * S + ip];
     }
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        const int q = qbase + tid + 256 * i;
+    for (int i = 0; i < PP_Q; i++) {
+        const int q = qbase + tid + PP_NT * i;
         if (q < r.mp) {
             d.P0[i] = *reinterpret_cast<const d2_t *>(P + (long)(2 * r.lp) * m + 2 * q);
             d.P1[i] = *reinterpret_cast<const d2_t *>(P + (long)(2 * r.lp + 1) * m + 2 * q);
@@ -302,7 +304,7 @@ __device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PP
 
 __device__ __forceinline__ void pp_accumulate(const PPData &d, double *strip, int c0, int cp0, int cp1, int cp2) {
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < PP_Q; i++) {
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             const int cq = d.cq[i][b];
@@ -316,7 +318,7 @@ __device__ __forceinline__ void pp_accumulate(const PPData &d, double *strip, in
     }
 }
 
-__global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const int32_t *__restrict__ pt_ip_begin,
+__global__ __launch_bounds__(PP_NT) void blk_pp_gather_kernel(DevProblem p, const int32_t *__restrict__ pt_ip_begin,
                                                             const PPRecord *__restrict__ recs,
                                                             const int32_t *__restrict__ ipcol,
                                                             const double *__restrict__ rowsA, double sigma2,
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const 
     const int rmax = max(cp0, max(cp1, cp2));
     const int ob = pt_ip_begin[pt], oe = pt_ip_begin[pt + 1];
     if (rmax < c0 || ob == oe) return;
-    for (int i = tid; i < 3 * PP_CW; i += 256) strip[i] = 0.0;
+    for (int i = tid; i < 3 * PP_CW; i += PP_NT) strip[i] = 0.0;
     PPRecord rec = recs[ob];
     PPRecord rec_next = recs[min(ob + 1, oe - 1)];
     PPData cur, nxt;
@@ -338,8 +340,8 @@ __global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const 
         const PPRecord rec_after = recs[min(o + 2, oe - 1)];
         if (o + 1 < oe) pp_load(nxt, p, rec_next, ipcol, rowsA, sigma2, tid, 0);
         pp_accumulate(cur, strip, c0, cp0, cp1, cp2);
-        // images with more than 512 points: the remaining chunks without prefetch
-        for (int qb = 512; qb < rec.mp; qb += 512) {
+        // images with more than PP_NT * PP_Q points: the remaining chunks without prefetch
+        for (int qb = PP_NT * PP_Q; qb < rec.mp; qb += PP_NT * PP_Q) {
             PPData extra;
             pp_load(extra, p, rec, ipcol, rowsA, sigma2, tid, qb);
             pp_accumulate(extra, strip, c0, cp0, cp1, cp2);
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(256) void blk_pp_gather_kernel(DevProblem p, const 
         if (r < 0) continue;
         const int cend = min(PP_CW, r - c0 + 1);
         double *nrow = N + (long)r * p.ld + c0;
-        for (int c = tid; c < cend; c += 256) {
+        for (int c = tid; c < cend; c += PP_NT) {
             const double v = strip[a * PP_CW + c];
             if (v != 0.0) nrow[c] += v;
         }
@@ -551,7 +553,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
                        ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
     if (pp.pt_ip_begin) {
-        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(256), 0, s, q, pp.pt_ip_begin,
+        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp.pt_ip_begin,
                            pp.recs, pp.ipcol, rowsA, s2, N, pp.cmin);
     } else {
         const int mp = max_m / 2;
