@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(jaicov_(?:neq|dense)_[a-z_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b(jaicov_(?:neq|dense)_[a-z_0-9]+)\s*\(", src)))
 
 
 def test_library_exports_every_declared_symbol():
