@@ -457,10 +457,13 @@ hipEvent_t DenseSolver::next_event() {
 // kernel (which needs a whole CU's LDS and would otherwise starve behind the trailing update's workgroups) runs there,
 // chained with events.
 hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
-    const bool split = dstream != nullptr && st == pstream;
+    // In the tail (short trailing updates, the panel chain is the critical path) the diagonal kernel stays on the panel
+    // stream: the two event hops per block cost more than the contention they avoid.
+    static const int tail_rows = getenv("JAICOV_TAIL_ROWS") ? atoi(getenv("JAICOV_TAIL_ROWS")) : 6144;
     for (int k = K0; k < K1; k++) {
         double *Akk = L + (long)(k * 128) * ld + k * 128;
         const int rows_k = n - k * 128;
+        const bool split = dstream != nullptr && st == pstream && rows_k > tail_rows;
         if (k > K0) {
             GemmArgs c{};
             c.A = L + (long)(k * 128) * ld + K0 * 128; c.lda = ld;      // L[k*128:n, K0*128 : k*128]
@@ -514,6 +517,7 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
 
 hipError_t DenseSolver::potrf() {
     const int nb = n / 128;
+    if (const char *e = getenv("JAICOV_NBO")) nbo = atoi(e);
     const int bo = nbo / 128 > 0 ? nbo / 128 : 1;
     const int S = (nb + bo - 1) / bo;
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));

@@ -25,7 +25,7 @@ typedef double d2_t __attribute__((ext_vector_type(2)));
 enum { LAY_KC = 0, LAY_XC = 1 };
 enum { KMODE_FULL = 0, KMODE_LE_ROW = 1, KMODE_GE_ROW = 2, KMODE_GE_COL = 3 };
 
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 16, GEMM_LDS_LD = 144;
+constexpr int GEMM_BK = 16;
 
 struct GemmArgs {
     const double *A, *B;
@@ -38,9 +38,17 @@ struct GemmArgs {
     long strideA, strideB, strideC;  // batch strides (blockIdx.y)
 };
 
-template <int ALAY, int BLAY>
-__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-    __shared__ double smem[2 * 2 * GEMM_BK * GEMM_LDS_LD];  // [stage][operand][k][x]
+// TM = 128: the throughput tile described above.  TM = 64: latency variant for launches that cannot fill the chip with
+// 128-tiles (panel GEMMs of the factorisation): 4x the workgroups, each wave 32x32 = 2x2 MFMA tiles, LDS stride 80.
+template <int ALAY, int BLAY, int TM = 128, int TN = 128>
+__global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void gemm_f64_kernel(GemmArgs g) {
+    constexpr int GEMM_BM = TM, GEMM_BN = TN;
+    constexpr int LDA_S = TM + 16, LDB_S = TN + 16;   // LDS row strides: == 16 mod 32 doubles -> conflict-free fragments
+    constexpr int MTM = TM / 32, MTN = TN / 32;       // MFMA tiles per wave
+    constexpr int EPA = TM / 16, EPB = TN / 16;       // doubles per thread and stage
+    constexpr int WTM = TM / 2, WTN = TN / 2;         // wave tile
+    constexpr int STAGE = GEMM_BK * (LDA_S + LDB_S);
+    __shared__ double smem[2 * STAGE];  // [stage][A: k][x] [B: k][x]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -76,81 +84,80 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     long astep, bstep;
     int a_lds, b_lds;  // LDS element offset of this thread's first element
     if (ALAY == LAY_KC) {
-        const int row = tid & 127, kh = tid >> 7;
-        ap = A + (m0 + row) * g.lda + kbeg + 8 * kh;
+        const int row = tid & (TM - 1), kh = tid / TM;
+        ap = A + (m0 + row) * g.lda + kbeg + EPA * kh;
         astep = GEMM_BK;
-        a_lds = (8 * kh) * GEMM_LDS_LD + row;
+        a_lds = (EPA * kh) * LDA_S + row;
     } else {
         const int kr = tid >> 4, ms = tid & 15;
-        ap = A + (long)(kbeg + kr) * g.lda + m0 + 8 * ms;
+        ap = A + (long)(kbeg + kr) * g.lda + m0 + EPA * ms;
         astep = (long)GEMM_BK * g.lda;
-        a_lds = kr * GEMM_LDS_LD + 8 * ms;
+        a_lds = kr * LDA_S + EPA * ms;
     }
     if (BLAY == LAY_KC) {
-        const int row = tid & 127, kh = tid >> 7;
-        bp = B + (n0 + row) * g.ldb + kbeg + 8 * kh;
+        const int row = tid & (TN - 1), kh = tid / TN;
+        bp = B + (n0 + row) * g.ldb + kbeg + EPB * kh;
         bstep = GEMM_BK;
-        b_lds = (8 * kh) * GEMM_LDS_LD + row;
+        b_lds = (EPB * kh) * LDB_S + row;
     } else {
         const int kr = tid >> 4, ns = tid & 15;
-        bp = B + (long)(kbeg + kr) * g.ldb + n0 + 8 * ns;
+        bp = B + (long)(kbeg + kr) * g.ldb + n0 + EPB * ns;
         bstep = (long)GEMM_BK * g.ldb;
-        b_lds = kr * GEMM_LDS_LD + 8 * ns;
+        b_lds = kr * LDB_S + EPB * ns;
     }
 
-    d2_t ra[4], rb[4];
+    d2_t ra[EPA / 2], rb[EPB / 2];
     auto gload = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            ra[j] = *reinterpret_cast<const d2_t *>(ap + 2 * j);
-            rb[j] = *reinterpret_cast<const d2_t *>(bp + 2 * j);
-        }
+        for (int j = 0; j < EPA / 2; j++) ra[j] = *reinterpret_cast<const d2_t *>(ap + 2 * j);
+#pragma unroll
+        for (int j = 0; j < EPB / 2; j++) rb[j] = *reinterpret_cast<const d2_t *>(bp + 2 * j);
         ap += astep;
         bp += bstep;
     };
     auto lstore = [&](int stage) {
-        double *sa = smem + (stage * 2 + 0) * GEMM_BK * GEMM_LDS_LD + a_lds;
-        double *sb = smem + (stage * 2 + 1) * GEMM_BK * GEMM_LDS_LD + b_lds;
+        double *sa = smem + stage * STAGE + a_lds;
+        double *sb = smem + stage * STAGE + GEMM_BK * LDA_S + b_lds;
         if (ALAY == LAY_KC) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                sa[(2 * j) * GEMM_LDS_LD] = ra[j].x;
-                sa[(2 * j + 1) * GEMM_LDS_LD] = ra[j].y;
+            for (int j = 0; j < EPA / 2; j++) {
+                sa[(2 * j) * LDA_S] = ra[j].x;
+                sa[(2 * j + 1) * LDA_S] = ra[j].y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<d2_t *>(sa + 2 * j) = ra[j];
+            for (int j = 0; j < EPA / 2; j++) *reinterpret_cast<d2_t *>(sa + 2 * j) = ra[j];
         }
         if (BLAY == LAY_KC) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                sb[(2 * j) * GEMM_LDS_LD] = rb[j].x;
-                sb[(2 * j + 1) * GEMM_LDS_LD] = rb[j].y;
+            for (int j = 0; j < EPB / 2; j++) {
+                sb[(2 * j) * LDB_S] = rb[j].x;
+                sb[(2 * j + 1) * LDB_S] = rb[j].y;
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) *reinterpret_cast<d2_t *>(sb + 2 * j) = rb[j];
+            for (int j = 0; j < EPB / 2; j++) *reinterpret_cast<d2_t *>(sb + 2 * j) = rb[j];
         }
     };
 
     // accumulators start from (beta/alpha)*C, so the epilogue is a pure store (alpha*acc): the C tile is fetched while
     // the first operand tiles are still in flight instead of as a dependent read-modify-write at the end.
     const double alpha = g.alpha, beta = g.beta;
-    double *cbase = C + (m0 + 64 * wr + (lane >> 4)) * g.ldc + n0 + 64 * wc + (lane & 15);
-    d4_t acc[4][4];
+    double *cbase = C + (m0 + WTM * wr + (lane >> 4)) * g.ldc + n0 + WTN * wc + (lane & 15);
+    d4_t acc[MTM][MTN];
     if (beta != 0.0) {
         const double bs = beta / alpha;
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < MTM; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < MTN; j++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) acc[i][j][r] = bs * cbase[(long)(16 * i + 4 * r) * g.ldc + 16 * j];
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++)
+        for (int i = 0; i < MTM; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < MTN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
 
     const int nk = (kend - kbeg) / GEMM_BK;
@@ -158,24 +165,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         gload();
         lstore(0);
         __syncthreads();
-        const int fa = (lane >> 4) * GEMM_LDS_LD + 64 * wr + (lane & 15);
-        const int fb = (lane >> 4) * GEMM_LDS_LD + 64 * wc + (lane & 15);
+        const int fa = (lane >> 4) * LDA_S + WTM * wr + (lane & 15);
+        const int fb = (lane >> 4) * LDB_S + WTN * wc + (lane & 15);
         for (int kt = 0; kt < nk; kt++) {
             const int st = kt & 1;
             if (kt + 1 < nk) gload();
-            const double *sa = smem + (st * 2 + 0) * GEMM_BK * GEMM_LDS_LD + fa;
-            const double *sb = smem + (st * 2 + 1) * GEMM_BK * GEMM_LDS_LD + fb;
+            const double *sa = smem + st * STAGE + fa;
+            const double *sb = smem + st * STAGE + GEMM_BK * LDA_S + fb;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
-                double a[4], b[4];
+                double a[MTM], b[MTN];
 #pragma unroll
-                for (int i = 0; i < 4; i++) a[i] = sa[(4 * ks) * GEMM_LDS_LD + 16 * i];
+                for (int i = 0; i < MTM; i++) a[i] = sa[(4 * ks) * LDA_S + 16 * i];
 #pragma unroll
-                for (int j = 0; j < 4; j++) b[j] = sb[(4 * ks) * GEMM_LDS_LD + 16 * j];
+                for (int j = 0; j < MTN; j++) b[j] = sb[(4 * ks) * LDB_S + 16 * j];
 #pragma unroll
-                for (int i = 0; i < 4; i++)
+                for (int i = 0; i < MTM; i++)
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
+                    for (int j = 0; j < MTN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
             }
             if (kt + 1 < nk) lstore(st ^ 1);
@@ -185,18 +192,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 
     // ---- epilogue ------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < MTM; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+        for (int j = 0; j < MTN; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) cbase[(long)(16 * i + 4 * r) * g.ldc + 16 * j] = alpha * acc[i][j][r];
 }
 
-inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1) {
+// Launches that cannot give every CU two 128-tiles (the regime in which the 128-tile runs at its rate) take the
+// 64-tile latency variant; `small_tiles` < 0 = that rule, 0 = never, 1 = always (rectangular KMODE_FULL calls only).
+constexpr int GEMM_SMALL_TILE_LIMIT = 480;
+inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1, int small_tiles = -1) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
-    const int tm = g.M / GEMM_BM, tn = g.N / GEMM_BN;
+    const int tm = g.M / 128, tn = g.N / 128;
     const int tiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
     dim3 grid(tiles, batch), block(256);
+    const bool can_small = !g.lower_only && g.kmode == KMODE_FULL && alay == LAY_KC && blay == LAY_KC;
+    if (can_small && (small_tiles > 0 || (small_tiles < 0 && tiles * batch < GEMM_SMALL_TILE_LIMIT))) {
+        if (g.C == g.A || g.C == g.B) {   // in place (one column tile): keep the whole row of C in one workgroup
+            if (tn != 1) return hipErrorInvalidValue;
+            grid.x = tiles * 2;
+            hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 128>), grid, block, 0, s, g);
+        } else {
+            grid.x = tiles * 4;
+            hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 64>), grid, block, 0, s, g);
+        }
+        return hipGetLastError();
+    }
     if (alay == LAY_KC && blay == LAY_KC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC>), grid, block, 0, s, g);
     else if (alay == LAY_KC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_XC>), grid, block, 0, s, g);
     else if (alay == LAY_XC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_XC, LAY_XC>), grid, block, 0, s, g);
