@@ -255,101 +255,105 @@ __global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t
 }
 
 // B4': point x point blocks without atomics.  One workgroup owns the rows of ONE object point p (3 rows of N) for a
-// chunk of PP_CW columns and keeps that strip in LDS; it walks the images that observe p, streams the two rows of the
-// image's Dinv that belong to p (coalesced) and adds A_p' Dinv_pq A_q for every point q of the image into the strip.
-// Inside one image all q are distinct points, so the LDS updates never collide; a barrier separates images.  The strip
-// is added to N (lower part, c <= r) once at the end: every entry of the point-point block has exactly one owner, the
-// sum order is fixed (images ascending) -> bitwise reproducible, no memory-side atomics.
-// The walk is software-pipelined: the loads of image o+1 (one 32-byte record, then Dinv rows / columns / Jacobian rows
-// of up to 512 points, two per thread) are in flight while image o is accumulated.
-constexpr int PP_CW = 4992;
-constexpr int PP_NT = 512;       // threads per workgroup of the gather
-constexpr int PP_Q = 1;          // points per thread and pass (PP_NT * PP_Q points of an image per pass)
+// chunk of PP_CW columns and keeps that strip in LDS (39 KB: four workgroups per CU hide each other's latency); it
+// walks the images that observe p and adds A_p' P_pq A_q for the points q of the image whose columns fall into the
+// chunk and do not exceed the row's own (lower triangle).  The engine stores a dense block in column order, so these q
+// are a contiguous range (PPGather::range, built at create) and the weight entries P_pq are streamed exactly once over
+// the whole launch: 2 x 2 doubles per point pair.  Inside one image all q are distinct points, so the LDS updates never
+// collide; a barrier separates images.  The strip is added to N once at the end: every entry of the point-point block
+// has exactly one owner and the sum order is fixed (images ascending) -> reproducible, no memory-side atomics.
+// The walk is software-pipelined: record and range of image o+2 and the operands of image o+1 are in flight while
+// image o is accumulated.
+constexpr int PP_NT = 128;       // threads per workgroup of the gather
 
-struct PPData {           // what one thread needs of one image: PP_Q points q = tid + PP_NT * i
-    d2_t P0[PP_Q], P1[PP_Q];
-    double aq[PP_Q][6];
-    int cq[PP_Q][3];
-    double ap0[3], ap1[3];
+struct PPData {           // what one thread needs of one partner point q
+    d2_t P0, P1;
+    double aq[6];
+    int cq[3];
 };
 
-__device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PPRecord &r, const int32_t *__restrict__ ipcol,
-                                        const double *__restrict__ rowsA, double sigma2, int tid, int qbase) {
+__device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PPRecord &r,
+                                        const int32_t *__restrict__ ipcol, const double *__restrict__ rowsA, int q, int qend) {
     const long S = p.n_ip;
-    const int m = 2 * r.mp;
-    const double *P = p.blk_w + r.poff;
-    const int ip = r.ipb + r.lp;
-#pragma unroll
-    for (int a = 0; a < 3; a++) {
-        d.ap0[a] = sigma2 * rowsA[(long)(2 * a) * S + ip];
-        d.ap1[a] = sigma2 * rowsA[(long)(2 * a + 1) * S + ip];
-    }
-#pragma unroll
-    for (int i = 0; i < PP_Q; i++) {
-        const int q = qbase + tid + PP_NT * i;
-        if (q < r.mp) {
-            d.P0[i] = *reinterpret_cast<const d2_t *>(P + (long)(2 * r.lp) * m + 2 * q);
-            d.P1[i] = *reinterpret_cast<const d2_t *>(P + (long)(2 * r.lp + 1) * m + 2 * q);
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                d.cq[i][b] = ipcol[3 * (long)(r.ipb + q) + b];
-                d.aq[i][2 * b] = rowsA[(long)(2 * b) * S + r.ipb + q];
-                d.aq[i][2 * b + 1] = rowsA[(long)(2 * b + 1) * S + r.ipb + q];
-            }
-        } else {
-            d.cq[i][0] = d.cq[i][1] = d.cq[i][2] = -1;
-        }
-    }
-}
-
-__device__ __forceinline__ void pp_accumulate(const PPData &d, double *strip, int c0, int cp0, int cp1, int cp2) {
-#pragma unroll
-    for (int i = 0; i < PP_Q; i++) {
+    if (q < qend) {
+        const int m = 2 * r.mp;
+        const double *P = p.blk_w + r.poff + (long)(2 * r.lp) * m + 2 * q;
+        d.P0 = *reinterpret_cast<const d2_t *>(P);
+        d.P1 = *reinterpret_cast<const d2_t *>(P + m);
 #pragma unroll
         for (int b = 0; b < 3; b++) {
-            const int cq = d.cq[i][b];
-            if (cq < c0 || cq >= c0 + PP_CW) continue;
-            const double g0 = d.P0[i].x * d.aq[i][2 * b] + d.P0[i].y * d.aq[i][2 * b + 1];
-            const double g1 = d.P1[i].x * d.aq[i][2 * b] + d.P1[i].y * d.aq[i][2 * b + 1];
-            if (cp0 >= cq) strip[cq - c0] += d.ap0[0] * g0 + d.ap1[0] * g1;
-            if (cp1 >= cq) strip[PP_CW + cq - c0] += d.ap0[1] * g0 + d.ap1[1] * g1;
-            if (cp2 >= cq) strip[2 * PP_CW + cq - c0] += d.ap0[2] * g0 + d.ap1[2] * g1;
+            d.cq[b] = ipcol[3 * (long)(r.ipb + q) + b];
+            d.aq[2 * b] = rowsA[(long)(2 * b) * S + r.ipb + q];
+            d.aq[2 * b + 1] = rowsA[(long)(2 * b + 1) * S + r.ipb + q];
         }
+    } else {
+        d.cq[0] = d.cq[1] = d.cq[2] = -1;
     }
 }
 
-__global__ __launch_bounds__(PP_NT) void blk_pp_gather_kernel(DevProblem p, const int32_t *__restrict__ pt_ip_begin,
-                                                            const PPRecord *__restrict__ recs,
-                                                            const int32_t *__restrict__ ipcol,
-                                                            const double *__restrict__ rowsA, double sigma2,
-                                                            double *__restrict__ N, int cmin) {
+__device__ __forceinline__ void pp_load_row(double (&ap)[6], const DevProblem &p, const PPRecord &r,
+                                            const double *__restrict__ rowsA, double sigma2) {
+    const long S = p.n_ip;
+    const int ip = r.ipb + r.lp;
+#pragma unroll
+    for (int a = 0; a < 6; a++) ap[a] = sigma2 * rowsA[(long)a * S + ip];
+}
+
+__device__ __forceinline__ void pp_accumulate(const PPData &d, const double (&ap)[6], double *strip, int c0, int cp0, int cp1,
+                                              int cp2) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int cq = d.cq[b];
+        if (cq < c0 || cq >= c0 + PP_CW) continue;
+        const double g0 = d.P0.x * d.aq[2 * b] + d.P0.y * d.aq[2 * b + 1];
+        const double g1 = d.P1.x * d.aq[2 * b] + d.P1.y * d.aq[2 * b + 1];
+        if (cp0 >= cq) strip[cq - c0] += ap[0] * g0 + ap[1] * g1;
+        if (cp1 >= cq) strip[PP_CW + cq - c0] += ap[2] * g0 + ap[3] * g1;
+        if (cp2 >= cq) strip[2 * PP_CW + cq - c0] += ap[4] * g0 + ap[5] * g1;
+    }
+}
+
+__global__ __launch_bounds__(PP_NT) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
+                                                            double sigma2, double *__restrict__ N) {
     __shared__ double strip[3 * PP_CW];
-    const int pt = blockIdx.x, tid = threadIdx.x;
-    const int c0 = cmin + blockIdx.y * PP_CW;
+    const int pt = blockIdx.x, tid = threadIdx.x, chunk = blockIdx.y, nch = pp.n_chunks;
+    const int c0 = pp.cmin + chunk * PP_CW;
     const int cp0 = p.point_col[3 * pt], cp1 = p.point_col[3 * pt + 1], cp2 = p.point_col[3 * pt + 2];
     const int rmax = max(cp0, max(cp1, cp2));
-    const int ob = pt_ip_begin[pt], oe = pt_ip_begin[pt + 1];
+    const int ob = pp.pt_ip_begin[pt], oe = pp.pt_ip_begin[pt + 1];
     if (rmax < c0 || ob == oe) return;
+    const int2 *range = reinterpret_cast<const int2 *>(pp.range);
     for (int i = tid; i < 3 * PP_CW; i += PP_NT) strip[i] = 0.0;
-    PPRecord rec = recs[ob];
-    PPRecord rec_next = recs[min(ob + 1, oe - 1)];
+    PPRecord r1 = pp.recs[ob];
+    int2 g1 = range[(long)ob * nch + chunk];
+    const int o1 = min(ob + 1, oe - 1);
+    PPRecord r2 = pp.recs[o1];
+    int2 g2 = range[(long)o1 * nch + chunk];
     PPData cur, nxt;
-    pp_load(cur, p, rec, ipcol, rowsA, sigma2, tid, 0);
+    double apc[6], apn[6];
+    pp_load(cur, p, r1, pp.ipcol, rowsA, g1.x + tid, g1.y);
+    pp_load_row(apc, p, r1, rowsA, sigma2);
     __syncthreads();
     for (int o = ob; o < oe; o++) {
-        const PPRecord rec_after = recs[min(o + 2, oe - 1)];
-        if (o + 1 < oe) pp_load(nxt, p, rec_next, ipcol, rowsA, sigma2, tid, 0);
-        pp_accumulate(cur, strip, c0, cp0, cp1, cp2);
-        // images with more than PP_NT * PP_Q points: the remaining chunks without prefetch
-        for (int qb = PP_NT * PP_Q; qb < rec.mp; qb += PP_NT * PP_Q) {
+        const int o2 = min(o + 2, oe - 1);
+        const PPRecord r3 = pp.recs[o2];
+        const int2 g3 = range[(long)o2 * nch + chunk];
+        if (o + 1 < oe) {
+            pp_load(nxt, p, r2, pp.ipcol, rowsA, g2.x + tid, g2.y);
+            pp_load_row(apn, p, r2, rowsA, sigma2);
+        }
+        pp_accumulate(cur, apc, strip, c0, cp0, cp1, cp2);
+        // ranges longer than the workgroup: the remaining passes without prefetch
+        for (int j = g1.x + PP_NT + tid; j < g1.y; j += PP_NT) {
             PPData extra;
-            pp_load(extra, p, rec, ipcol, rowsA, sigma2, tid, qb);
-            pp_accumulate(extra, strip, c0, cp0, cp1, cp2);
+            pp_load(extra, p, r1, pp.ipcol, rowsA, j, g1.y);
+            pp_accumulate(extra, apc, strip, c0, cp0, cp1, cp2);
         }
         __syncthreads();
         cur = nxt;
-        rec = rec_next;
-        rec_next = rec_after;
+#pragma unroll
+        for (int a = 0; a < 6; a++) apc[a] = apn[a];
+        r1 = r2; g1 = g2; r2 = r3; g2 = g3;
     }
     const int cps[3] = {cp0, cp1, cp2};
 #pragma unroll
@@ -553,8 +557,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
                        ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
     if (pp.pt_ip_begin) {
-        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp.pt_ip_begin,
-                           pp.recs, pp.ipcol, rowsA, s2, N, pp.cmin);
+        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp, rowsA, s2, N);
     } else {
         const int mp = max_m / 2;
         hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, q, blk_list, rowsA, s2, N);

@@ -43,10 +43,15 @@ struct PPRecord {          // one (object point, image block) incidence, 32 byte
     int64_t poff;               // offset of the block's Dinv in blk_w
     int64_t pad2;
 };
+constexpr int PP_CW = 1664;   // columns of one LDS strip of the point x point gather (3 rows x PP_CW doubles = 39 KB)
 struct PPGather {
     const int32_t *pt_ip_begin = nullptr;   // [n_points+1] CSR over recs
     const PPRecord *recs = nullptr;         // image order within a point
     const int32_t *ipcol = nullptr;         // [3*n_ip] column of X,Y,Z of the point seen by image point ip
+    // the engine stores the points of a dense block in column order, so the partners that fall into column chunk c of
+    // record o are the block positions range[2*(o*n_chunks+c)] .. range[..+1] (already cut at the row's own column:
+    // only the lower triangle is assembled)
+    const int32_t *range = nullptr;
     int cmin = 0, n_chunks = 0;
 };
 

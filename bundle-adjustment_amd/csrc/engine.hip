@@ -122,12 +122,17 @@ __global__ void gather_sub_kernel(const double *__restrict__ Q, long ld, const i
     out[t] = i >= j ? Q[(long)i * ld + j] : Q[(long)j * ld + i];
 }
 // dense dispersion (row-major m x m) -> padded lower square with identity padding
-__global__ void load_disp_kernel(const double *__restrict__ D, int m, double *__restrict__ L, long ld, int mp) {
+// perm (optional): engine point position -> caller's point position inside the block (rows 2q, 2q+1 move together)
+__global__ void load_disp_kernel(const double *__restrict__ D, int m, double *__restrict__ L, long ld, int mp,
+                                 const int32_t *__restrict__ perm) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
     if (j >= mp) return;
     double v = (i == j) ? 1.0 : 0.0;
-    if (i < m && j < m) v = D[(long)i * m + j];
+    if (i < m && j < m) {
+        const int si = perm ? 2 * perm[i >> 1] + (i & 1) : i, sj = perm ? 2 * perm[j >> 1] + (j & 1) : j;
+        v = D[(long)si * m + sj];
+    }
     L[(long)i * ld + j] = v;
 }
 __global__ void store_inv_kernel(const double *__restrict__ Q, long ld, int m, double *__restrict__ out) {
@@ -161,6 +166,7 @@ struct jaicov_engine {
     // EO pre-elimination (schur.hip)
     bool schur_ok = false, schur_active = false, want_inverse_next = false;
     std::vector<int> h_blk_images;   // image of every block handled by this engine
+    std::vector<int32_t> ip_old2new; // empty, or: engine position of the caller's observation (dense blocks are column-sorted)
     int e0 = 0;                   // first EO column == order of the reduced system
     SchurBufs sb;
     double *d_xE = nullptr;
@@ -232,9 +238,10 @@ static int check_device(std::string &err) {
 }
 
 // inverse of a dense SPD dispersion on the device: out (m x m row-major, device) = D^-1
-static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_D, int m, double *d_out) {
+static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_D, int m, double *d_out,
+                             const int32_t *d_perm = nullptr) {
     const int mp = ds.n;
-    hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp);
+    hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp, d_perm);
     HIPE(e, ds.potrf());
     HIPE(e, ds.trtri());
     HIPE(e, ds.lauum());
@@ -261,7 +268,11 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     delete e;
 }
 
-static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jaicov_engine_options *opts) {
+static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const jaicov_engine_options *opts) {
+    const jaicov_problem_desc *D = D_in;
+    jaicov_problem_desc Dperm;   // the description with the observations of dense image blocks in column order
+    std::vector<int32_t> pv_image, pv_point, perm_local;
+    std::vector<double> pv_x, pv_y, pv_vx, pv_vy, pv_rho;
     HIPE(e, hipSetDevice(e->device));
     hipDeviceProp_t prop;
     HIPE(e, hipGetDeviceProperties(&prop, e->device));
@@ -343,6 +354,50 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
         ip = en;
     }
     w_total_saved = w_total;
+    // ---- column-sorted storage inside dense image blocks -------------------------------------------------------
+    // The point x point gather (assemble.hip) streams, for one object point and one range of columns, the weights of
+    // the partner points of an image; with the image's observations stored in the order of their points' columns
+    // those partners are contiguous.  The engine therefore keeps the observations of every dense block (and the
+    // block's dispersion) in column order; e->ip_old2new maps the caller's observation index for get_rows().
+    {
+        const int NOCOL = 1 << 30;
+        auto key = [&](int ip) {
+            int k = NOCOL;
+            for (int a = 0; a < 3; a++) {
+                const int c = D->point_col[3 * D->ip_point[ip] + a];
+                if (c >= 0) k = std::min(k, c);
+            }
+            return k;
+        };
+        std::vector<int32_t> new2old(D->n_image_points);
+        for (int ip = 0; ip < D->n_image_points; ip++) new2old[ip] = ip;
+        bool permuted = false;
+        for (int g : blk_list) {
+            const int b = D->blk_ip_begin[g], en = D->blk_ip_begin[g + 1];
+            std::vector<int> k(en - b);
+            for (int ip = b; ip < en; ip++) k[ip - b] = key(ip);
+            std::stable_sort(new2old.begin() + b, new2old.begin() + en, [&](int x, int y) { return k[x - b] < k[y - b]; });
+            for (int ip = b; ip < en && !permuted; ip++) permuted = new2old[ip] != ip;
+        }
+        if (permuted) {
+            const size_t n = (size_t)D->n_image_points;
+            pv_image.resize(n); pv_point.resize(n); pv_x.resize(n); pv_y.resize(n); pv_vx.resize(n); pv_vy.resize(n); pv_rho.resize(n);
+            perm_local.resize(n);
+            e->ip_old2new.resize(n);
+            for (size_t i = 0; i < n; i++) {
+                const int o = new2old[i];
+                pv_image[i] = D->ip_image[o]; pv_point[i] = D->ip_point[o]; pv_x[i] = D->ip_x[o]; pv_y[i] = D->ip_y[o];
+                pv_vx[i] = D->ip_var_x[o]; pv_vy[i] = D->ip_var_y[o]; pv_rho[i] = D->ip_rho[o];
+                e->ip_old2new[o] = (int32_t)i;
+            }
+            for (int g : blk_list)
+                for (int ip = D->blk_ip_begin[g]; ip < D->blk_ip_begin[g + 1]; ip++) perm_local[ip] = new2old[ip] - D->blk_ip_begin[g];
+            Dperm = *D;
+            Dperm.ip_image = pv_image.data(); Dperm.ip_point = pv_point.data(); Dperm.ip_x = pv_x.data(); Dperm.ip_y = pv_y.data();
+            Dperm.ip_var_x = pv_vx.data(); Dperm.ip_var_y = pv_vy.data(); Dperm.ip_rho = pv_rho.data();
+            D = &Dperm;
+        }
+    }
     for (int g : blk_list) e->h_blk_images.push_back(D->ip_image[D->blk_ip_begin[g]]);
     e->n_seg = (int)seg_b.size();
     e->n_blk_list = (int)blk_list.size();
@@ -418,11 +473,48 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
             std::vector<int32_t> ipcol((size_t)3 * D->n_image_points, -1);
             for (int ip : blk_ip_list)
                 for (int a = 0; a < 3; a++) ipcol[(size_t)3 * ip + a] = D->point_col[3 * D->ip_point[ip] + a];
+            // per record and column chunk: the range of partner positions (the block is stored in column order)
+            const int n_chunks = (cmax - cmin + PP_CW) / PP_CW;
+            const int NOCOL = 1 << 30;
+            std::vector<int32_t> lo_col(D->n_image_points, NOCOL), hi_col(D->n_image_points, -1);
+            for (int ip : blk_ip_list)
+                for (int a = 0; a < 3; a++) {
+                    const int c = ipcol[(size_t)3 * ip + a];
+                    if (c >= 0) { lo_col[ip] = std::min(lo_col[ip], c); hi_col[ip] = std::max(hi_col[ip], c); }
+                }
+            std::vector<int32_t> chunk_lo((size_t)blk_list.size() * n_chunks), chunk_hi((size_t)blk_list.size() * n_chunks);
+            std::vector<int32_t> blk_pos(D->n_image_blocks, -1);
+            for (size_t t = 0; t < blk_list.size(); t++) {
+                const int g = blk_list[t], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
+                blk_pos[g] = (int)t;
+                for (int j = 1; j < mp; j++)
+                    if (lo_col[ipb + j] < lo_col[ipb + j - 1]) FAIL(e, JAICOV_ERR_DEVICE, "internal: dense block not in column order");
+                for (int c = 0; c < n_chunks; c++) {
+                    const int c0 = cmin + c * PP_CW, c1 = c0 + PP_CW;
+                    int lo = mp, hi = 0;
+                    for (int j = 0; j < mp; j++)
+                        if (hi_col[ipb + j] >= c0 && lo_col[ipb + j] < c1) { lo = std::min(lo, j); hi = j + 1; }
+                    chunk_lo[t * n_chunks + c] = lo; chunk_hi[t * n_chunks + c] = std::max(hi, lo);
+                }
+            }
+            std::vector<int32_t> range((size_t)2 * list.size() * n_chunks);
+            for (size_t o = 0; o < list.size(); o++) {
+                const int ip = list[o], g = blk_of_ip[ip], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
+                const int t = blk_pos[g];
+                // partners whose first column is <= the largest row column of this point: a prefix of the block
+                const int qend = (int)(std::upper_bound(lo_col.begin() + ipb, lo_col.begin() + ipb + mp, hi_col[ip]) - (lo_col.begin() + ipb));
+                for (int c = 0; c < n_chunks; c++) {
+                    const int lo = chunk_lo[(size_t)t * n_chunks + c], hi = std::min(chunk_hi[(size_t)t * n_chunks + c], qend);
+                    range[2 * (o * n_chunks + c)] = lo;
+                    range[2 * (o * n_chunks + c) + 1] = std::max(hi, lo);
+                }
+            }
             if ((rc = upload(e, cnt.data(), cnt.size(), &e->pp.pt_ip_begin))) return rc;
             if ((rc = upload(e, recs.data(), recs.size(), &e->pp.recs))) return rc;
             if ((rc = upload(e, ipcol.data(), ipcol.size(), &e->pp.ipcol))) return rc;
+            if ((rc = upload(e, range.data(), range.size(), &e->pp.range))) return rc;
             e->pp.cmin = cmin;
-            e->pp.n_chunks = (cmax - cmin + 4992) / 4992;
+            e->pp.n_chunks = n_chunks;
         }
     }
 
@@ -453,6 +545,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
             const int mp = ((mmax + 127) / 128) * 128;
             HIPE(e, ds.init(e->stream, mp, true));
             double *d_tmp = nullptr;
+            const int32_t *d_perm_local = nullptr;
+            if (!perm_local.empty() && (rc = upload(e, perm_local.data(), perm_local.size(), &d_perm_local))) { ds.release(); return rc; }
             hipError_t he = hipMalloc(&d_tmp, (size_t)mmax * mmax * sizeof(double));
             if (he != hipSuccess) { ds.release(); HIPE(e, he); }
             int status = JAICOV_OK;
@@ -460,7 +554,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D, const jai
                 const int g = blk_list[t];
                 const int m = 2 * (D->blk_ip_begin[g + 1] - D->blk_ip_begin[g]);
                 hipMemcpyAsync(d_tmp, D->blk_disp + D->blk_disp_offset[g], (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, e->stream);
-                status = invert_dispersion(e, ds, d_tmp, m, d_w + blk_w_off[g]);
+                status = invert_dispersion(e, ds, d_tmp, m, d_w + blk_w_off[g], d_perm_local ? d_perm_local + D->blk_ip_begin[g] : nullptr);
             }
             for (int g = 0; g < D->n_direct_groups && status == JAICOV_OK; g++) {
                 if (dg_w_off[g] < 0) continue;
@@ -1018,7 +1112,7 @@ extern "C" int jaicov_neq_get_rows(jaicov_engine *e, int32_t ip_begin, int32_t i
     HIPE(e, hipMemcpyAsync(hW.data(), e->d_rowsW, hW.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     HIPE(e, hipStreamSynchronize(e->stream));
     for (int i = 0; i < ip_count; i++) {
-        const size_t ip = (size_t)ip_begin + i;
+        const size_t ip = e->ip_old2new.empty() ? (size_t)ip_begin + i : (size_t)e->ip_old2new[(size_t)ip_begin + i];
         w[2 * i] = hW[ip]; w[2 * i + 1] = hW[S + ip];
         for (int r = 0; r < 2; r++)
             for (int l = 0; l < KROW; l++) A[((size_t)2 * i + r) * KROW + l] = hA[(size_t)(2 * l + r) * S + ip];
@@ -1144,7 +1238,7 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
         hipMalloc(&d_X, (size_t)DENSE_MAX_RHS * np * sizeof(double));
         hipMemcpyAsync(d_ap, ap, len * sizeof(double), hipMemcpyHostToDevice, s);
         // identity padding, then unpack the lower triangle
-        hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np);
+        hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np, (const int32_t *)nullptr);
         hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, d_ap, ds.ld, n, ds.L);
         hipMemsetAsync(d_Yw, 0, (size_t)DENSE_MAX_RHS * np * sizeof(double), s);
         for (int q = 0; q < nrhs; q++) hipMemcpyAsync(d_Yw + (size_t)q * np, b + (size_t)q * n, n * sizeof(double), hipMemcpyHostToDevice, s);
@@ -1179,6 +1273,26 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
 
 namespace jaicov { hipError_t diag_kernel_bench(int dbg, int iters, float *ms_out); hipError_t mfma_peak_bench(int, int, float *, double *); }
 namespace jaicov { hipError_t cumask_bench(const uint32_t *, int, int, float *, double *); }
+// Per-workgroup timeline of one trailing-update shaped GEMM (C -= A A', K columns): out[8 * tiles]
+extern "C" int jaicov_debug_gemm_trace(int M, int K, int lower_only, long long *out) {
+    std::string err;
+    if (check_device(err)) return JAICOV_ERR_NO_DEVICE;
+    const int tm = M / 128, tiles = lower_only ? tm * (tm + 1) / 2 : tm * tm;
+    double *dA = nullptr, *dC = nullptr; long long *dT = nullptr;
+    hipMalloc(&dA, (size_t)M * K * 8); hipMalloc(&dC, (size_t)M * M * 8); hipMalloc(&dT, (size_t)tiles * 64);
+    hipMemset(dA, 0, (size_t)M * K * 8); hipMemset(dC, 0, (size_t)M * M * 8); hipMemset(dT, 0, (size_t)tiles * 64);
+    GemmArgs g{};
+    g.A = dA; g.B = dA; g.C = dC; g.lda = K; g.ldb = K; g.ldc = M; g.M = M; g.N = M; g.K = K;
+    g.alpha = -1.0; g.beta = 1.0; g.lower_only = lower_only; g.kmode = KMODE_FULL;
+    gemm_f64(nullptr, LAY_KC, LAY_KC, g);
+    g.trace = dT;
+    hipError_t he = gemm_f64(nullptr, LAY_KC, LAY_KC, g);
+    he = he == hipSuccess ? hipDeviceSynchronize() : he;
+    hipMemcpy(out, dT, (size_t)tiles * 64, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dC); hipFree(dT);
+    return he == hipSuccess ? JAICOV_OK : JAICOV_ERR_DEVICE;
+}
+
 extern "C" int jaicov_debug_cumask(const uint32_t *mask, int blocks, int iters, double *ms_out, double *tflops) {
     float ms = 0;
     hipError_t he = jaicov::cumask_bench(mask, blocks, iters, &ms, tflops);

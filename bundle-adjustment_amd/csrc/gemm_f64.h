@@ -36,12 +36,13 @@ struct GemmArgs {
     int lower_only;      // square tile grid: skip tiles with tile_col > tile_row
     int kmode;           // restrict the k range per tile (triangular operands), see KMODE_*
     long strideA, strideB, strideC;  // batch strides (blockIdx.y)
+    long long *trace;    // debug: per workgroup {start, loop begin, loop end, end} of the 100 MHz clock + hardware id
 };
 
 // TM = 128: the throughput tile described above.  TM = 64: latency variant for launches that cannot fill the chip with
 // 128-tiles (panel GEMMs of the factorisation): 4x the workgroups, each wave 32x32 = 2x2 MFMA tiles, LDS stride 80.
 template <int ALAY, int BLAY, int TM = 128, int TN = 128>
-__global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void gemm_f64_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(GemmArgs g) {
     constexpr int GEMM_BM = TM, GEMM_BN = TN;
     constexpr int LDA_S = TM + 16, LDB_S = TN + 16;   // LDS row strides: == 16 mod 32 doubles -> conflict-free fragments
     constexpr int MTM = TM / 32, MTN = TN / 32;       // MFMA tiles per wave
@@ -69,6 +70,8 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void gemm_f64_kernel(GemmAr
             tile_col = t - tile_row * tn;
         }
     }
+    long long t_start = 0, t_loop0 = 0, t_loop1 = 0;
+    if (g.trace) t_start = wall_clock64();
     const long m0 = (long)tile_row * GEMM_BM, n0 = (long)tile_col * GEMM_BN;
     int kbeg = 0, kend = g.K;
     if (g.kmode == KMODE_LE_ROW) kend = min(g.K, (tile_row + 1) * GEMM_BM);
@@ -161,6 +164,7 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void gemm_f64_kernel(GemmAr
     }
 
     const int nk = (kend - kbeg) / GEMM_BK;
+    if (g.trace) t_loop0 = wall_clock64();
     if (nk > 0) {
         gload();
         lstore(0);
@@ -191,12 +195,19 @@ __global__ __launch_bounds__(256, TM == 128 ? 2 : 4) void gemm_f64_kernel(GemmAr
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
+    if (g.trace) t_loop1 = wall_clock64();
 #pragma unroll
     for (int i = 0; i < MTM; i++)
 #pragma unroll
         for (int j = 0; j < MTN; j++)
 #pragma unroll
             for (int r = 0; r < 4; r++) cbase[(long)(16 * i + 4 * r) * g.ldc + 16 * j] = alpha * acc[i][j][r];
+    if (g.trace && tid == 0) {
+        long long *t = g.trace + 8 * ((long)blockIdx.y * gridDim.x + blockIdx.x);
+        t[0] = t_start; t[1] = t_loop0; t[2] = t_loop1; t[3] = wall_clock64();
+        t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+        t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+    }
 }
 
 // Launches that cannot give every CU two 128-tiles (the regime in which the 128-tile runs at its rate) take the
