@@ -120,44 +120,83 @@ __global__ __launch_bounds__(256) void assemble_small_kernel(DevProblem p, const
 // ---------------------------------------------------------------------------------------------------------------
 // image blocks (jointly dispersed image points of one image; weight = sigma2 * Dinv, Dinv dense m x m)
 // ---------------------------------------------------------------------------------------------------------------
-// B1: T = Dinv * [A_c | w]   (m x (kc+1)); thread = row r, P streamed once (symmetric: column r == row r, coalesced)
-__global__ __launch_bounds__(128) void blk_T_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
-                                                    const double *__restrict__ rowsA, const double *__restrict__ rowsW,
-                                                    double *__restrict__ T) {
-    __shared__ double Ac[64 * KC_LD];
+// B1: T = Dinv * [A_c | w]   (m x (kc+1)); P streamed once (symmetric: column r == row r, coalesced).  A thread owns
+// TR rows: the [A_c | w] values of a row k are the same for every lane and come from LDS as 16-byte broadcast reads, so
+// the LDS instruction count per byte of P (what bounds this kernel) falls with TR.
+constexpr int T_TR = 2, T_NT = 128, T_KB = 8;
+__global__ __launch_bounds__(T_NT) void blk_T_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                     const double *__restrict__ rowsA, const double *__restrict__ rowsW,
+                                                     double *__restrict__ T) {
+    __shared__ __attribute__((aligned(16))) double Ac[64 * KC_LD];
     const int g = blk_list[blockIdx.y];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
-    const int r = blockIdx.x * 128 + threadIdx.x;
-    if (blockIdx.x * 128 >= m) return;
+    const int rbase = blockIdx.x * (T_NT * T_TR) + threadIdx.x;
+    if ((int)blockIdx.x * (T_NT * T_TR) >= m) return;
     const long S = p.n_ip;
     const int img = p.ip_image[ipb], cam = p.image_camera[img];
     const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
     const double *P = p.blk_w + p.blk_w_offset[g];
-    double acc[KC_LD];
+    double acc[T_TR][KC_LD];
+    int rr_[T_TR];
+    double live[T_TR];
 #pragma unroll
-    for (int c = 0; c < KC_LD; c++) acc[c] = 0.0;
+    for (int t = 0; t < T_TR; t++) {
+        const int r = rbase + T_NT * t;
+        rr_[t] = min(r, m - 1);
+        live[t] = r < m ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < KC_LD; c++) acc[t][c] = 0.0;
+    }
     for (int k0 = 0; k0 < m; k0 += 64) {
         const int kn = min(64, m - k0);
         __syncthreads();
-        for (int idx = threadIdx.x; idx < kn * (kc + 1); idx += 128) {
+        for (int idx = threadIdx.x; idx < kn * KC_LD; idx += T_NT) {
             const int c = idx / kn, kk = idx - c * kn;
             const int k = k0 + kk, o = k >> 1, rr = k & 1;
-            Ac[kk * KC_LD + c] = (c < kc) ? rowsA[(long)(2 * shared_local(c) + rr) * S + ipb + o]
-                                          : rowsW[(long)rr * S + ipb + o];
+            double v = 0.0;
+            if (c < kc) v = rowsA[(long)(2 * shared_local(c) + rr) * S + ipb + o];
+            else if (c == kc) v = rowsW[(long)rr * S + ipb + o];
+            Ac[kk * KC_LD + c] = v;
         }
         __syncthreads();
-        if (r < m) {
-            for (int kk = 0; kk < kn; kk++) {
-                const double pk = P[(long)(k0 + kk) * m + r];
+        // P values of T_KB rows k are fetched ahead of the FMAs that use them (two batches in flight)
+        double pk[T_TR][T_KB], pn[T_TR][T_KB];
 #pragma unroll
-                for (int c = 0; c < KC_LD; c++) acc[c] += pk * Ac[kk * KC_LD + c];
+        for (int u = 0; u < T_KB; u++)
+#pragma unroll
+            for (int t = 0; t < T_TR; t++) pk[t][u] = P[(long)min(k0 + u, m - 1) * m + rr_[t]];
+        for (int kb = 0; kb < kn; kb += T_KB) {
+#pragma unroll
+            for (int u = 0; u < T_KB; u++)
+#pragma unroll
+                for (int t = 0; t < T_TR; t++) pn[t][u] = P[(long)min(k0 + kb + T_KB + u, m - 1) * m + rr_[t]];
+#pragma unroll
+            for (int u = 0; u < T_KB; u++) {
+                if (kb + u >= kn) break;
+#pragma unroll
+                for (int c = 0; c < KC_LD; c += 2) {
+                    const d2_t a = *reinterpret_cast<const d2_t *>(&Ac[(kb + u) * KC_LD + c]);
+#pragma unroll
+                    for (int t = 0; t < T_TR; t++) {
+                        acc[t][c] += pk[t][u] * a.x;
+                        acc[t][c + 1] += pk[t][u] * a.y;
+                    }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < T_KB; u++)
+#pragma unroll
+                for (int t = 0; t < T_TR; t++) pk[t][u] = pn[t][u];
         }
     }
-    if (r < m) {
-        double *out = T + ((long)2 * ipb + r) * KC_LD;
 #pragma unroll
-        for (int c = 0; c < KC_LD; c++) out[c] = acc[c];
+    for (int t = 0; t < T_TR; t++) {
+        const int r = rbase + T_NT * t;
+        if (r < m && live[t] != 0.0) {
+            double *out = T + ((long)2 * ipb + r) * KC_LD;
+#pragma unroll
+            for (int c = 0; c < KC_LD; c++) out[c] = acc[t][c];
+        }
     }
 }
 
@@ -542,7 +581,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
                                   double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb) {
     if (n_list <= 0) return hipSuccess;
     const int schur = sb.Pp != nullptr;
-    hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + 127) / 128, n_list), dim3(128), 0, s, p, blk_list, rowsA, rowsW, T);
+    hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
     DevProblem q = p;
     double s2 = sigma2;
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]

@@ -121,31 +121,47 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
     for (int i = tid; i < 6 * SCHUR_GLD; i += 256) G_out[(long)img * 6 * SCHUR_GLD + i] = Gs[i];
 }
 
-// P' = sigma2 * Dinv - U U'   (full symmetric m x m, row-major).  grid (ceil(m/64), ceil(m/16), n_list), block (64,4)
+// P' = sigma2 * Dinv - U U'   (row-major m x m; only the lower triangle including the 2 x 2 diagonal blocks is written:
+// the point x point assembly, its only reader, pairs a point with the partners stored before it).
+// grid (ceil(m/64), ceil(m/64), n_list), block (64,4): a 64 x 64 tile, thread = one column x 16 rows; the U rows of the
+// tile sit in LDS (the same for all lanes of a wave).
 __global__ __launch_bounds__(256) void blk_pprime_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
                                                          const double *__restrict__ Ubuf, double sigma2,
                                                          double *__restrict__ Pp) {
+    __shared__ __attribute__((aligned(16))) double Us[64 * 6];
     const int g = blk_list[blockIdx.z];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
+    if ((int)blockIdx.x * 64 >= m || (int)blockIdx.y * 64 >= m || blockIdx.x > blockIdx.y) return;
+    const int tid = threadIdx.y * 64 + threadIdx.x;
+    const int r0 = blockIdx.y * 64;
+    for (int i = tid; i < 64 * 6; i += 256) {
+        const int rr = i / 6, k = i - 6 * rr;
+        Us[i] = r0 + rr < m ? Ubuf[((long)2 * ipb + r0 + rr) * 8 + k] : 0.0;
+    }
+    __syncthreads();
     const int c = blockIdx.x * 64 + threadIdx.x;
-    if (blockIdx.x * 64 >= m || blockIdx.y * 16 >= m) return;
+    if (c >= m) return;
     const double *P = p.blk_w + p.blk_w_offset[g];
     double *Po = Pp + p.blk_w_offset[g];
     double uc[6];
-    if (c < m) {
+    {
         const double *u = Ubuf + ((long)2 * ipb + c) * 8;
 #pragma unroll
         for (int k = 0; k < 6; k++) uc[k] = u[k];
     }
+    double v[16];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = blockIdx.y * 16 + threadIdx.y * 4 + i;
-        if (r >= m || c >= m) continue;
-        const double *ur = Ubuf + ((long)2 * ipb + r) * 8;
-        double s = sigma2 * P[(long)r * m + c];
+    for (int i = 0; i < 16; i++) {
+        const int r = r0 + threadIdx.y * 16 + i;
+        v[i] = (r < m && c <= (r | 1)) ? P[(long)r * m + c] : 0.0;
+    }
 #pragma unroll
-        for (int k = 0; k < 6; k++) s -= ur[k] * uc[k];
-        Po[(long)r * m + c] = s;
+    for (int i = 0; i < 16; i++) {
+        const int rl = threadIdx.y * 16 + i, r = r0 + rl;
+        if (r >= m || c > (r | 1)) continue;
+        const d2_t u01 = *reinterpret_cast<const d2_t *>(&Us[rl * 6]), u23 = *reinterpret_cast<const d2_t *>(&Us[rl * 6 + 2]),
+                   u45 = *reinterpret_cast<const d2_t *>(&Us[rl * 6 + 4]);
+        Po[(long)r * m + c] = sigma2 * v[i] - (u01.x * uc[0] + u01.y * uc[1] + u23.x * uc[2] + u23.y * uc[3] + u45.x * uc[4] + u45.y * uc[5]);
     }
 }
 
@@ -254,7 +270,7 @@ hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int3
     if (n_list <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_elim_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T, sigma2, lambda, Ubuf,
                        Linv, G, info);
-    hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 15) / 16, n_list), dim3(64, 4), 0, s, p, blk_list,
+    hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 63) / 64, n_list), dim3(64, 4), 0, s, p, blk_list,
                        Ubuf, sigma2, Pp);
     if (lambda > 0.0 && diagcorr) {
         const long nt = (long)3 * n_ip_list + (long)n_list * SCHUR_GLD;
