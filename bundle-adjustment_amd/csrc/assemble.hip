@@ -293,18 +293,15 @@ __global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t
     }
 }
 
-// B4': point x point blocks without atomics.  One workgroup owns the rows of ONE object point p (3 rows of N) for a
-// chunk of PP_CW columns and keeps that strip in LDS (39 KB: four workgroups per CU hide each other's latency); it
-// walks the images that observe p and adds A_p' P_pq A_q for the points q of the image whose columns fall into the
-// chunk and do not exceed the row's own (lower triangle).  The engine stores a dense block in column order, so these q
-// are a contiguous range (PPGather::range, built at create) and the weight entries P_pq are streamed exactly once over
-// the whole launch: 2 x 2 doubles per point pair.  Inside one image all q are distinct points, so the LDS updates never
-// collide; a barrier separates images.  The strip is added to N once at the end: every entry of the point-point block
-// has exactly one owner and the sum order is fixed (images ascending) -> reproducible, no memory-side atomics.
-// The walk is software-pipelined: record and range of image o+2 and the operands of image o+1 are in flight while
-// image o is accumulated.
-constexpr int PP_NT = 128;       // threads per workgroup of the gather
-
+// B4': point x point blocks without memory-side atomics.  One workgroup owns the rows of ONE object point p (3 rows
+// of N) for a chunk of PP_CW columns and keeps that strip in LDS (39 KB: four workgroups per CU); its waves walk the
+// images that observe p (wave w takes every (PP_NT/64)-th image) and add A_p' P_pq A_q for the points q of the image
+// whose columns fall into the chunk and do not exceed the row's own (lower triangle).  The engine stores a dense block
+// in column order, so these q are a contiguous range (PPGather::range, built at create) and the weight entries P_pq are
+// streamed exactly once over the whole launch: 2 x 2 doubles per point pair.  Two images may share a partner point,
+// so the strip is updated with LDS atomics (ds_add_f64) and the waves never wait for each other; every wave keeps
+// record and range of its image after next and the operands of its next image in flight while it accumulates.
+// The strip is added to N once at the end: every entry of the point-point block has exactly one owner workgroup.
 struct PPData {           // what one thread needs of one partner point q
     d2_t P0, P1;
     double aq[6];
@@ -346,16 +343,17 @@ __device__ __forceinline__ void pp_accumulate(const PPData &d, const double (&ap
         if (cq < c0 || cq >= c0 + PP_CW) continue;
         const double g0 = d.P0.x * d.aq[2 * b] + d.P0.y * d.aq[2 * b + 1];
         const double g1 = d.P1.x * d.aq[2 * b] + d.P1.y * d.aq[2 * b + 1];
-        if (cp0 >= cq) strip[cq - c0] += ap[0] * g0 + ap[1] * g1;
-        if (cp1 >= cq) strip[PP_CW + cq - c0] += ap[2] * g0 + ap[3] * g1;
-        if (cp2 >= cq) strip[2 * PP_CW + cq - c0] += ap[4] * g0 + ap[5] * g1;
+        if (cp0 >= cq) unsafeAtomicAdd(&strip[cq - c0], ap[0] * g0 + ap[1] * g1);
+        if (cp1 >= cq) unsafeAtomicAdd(&strip[PP_CW + cq - c0], ap[2] * g0 + ap[3] * g1);
+        if (cp2 >= cq) unsafeAtomicAdd(&strip[2 * PP_CW + cq - c0], ap[4] * g0 + ap[5] * g1);
     }
 }
 
 __global__ __launch_bounds__(PP_NT) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             double sigma2, double *__restrict__ N) {
     __shared__ double strip[3 * PP_CW];
-    const int pt = blockIdx.x, tid = threadIdx.x, chunk = blockIdx.y, nch = pp.n_chunks;
+    constexpr int NW = PP_NT / 64;
+    const int pt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chunk = blockIdx.y, nch = pp.n_chunks;
     const int c0 = pp.cmin + chunk * PP_CW;
     const int cp0 = p.point_col[3 * pt], cp1 = p.point_col[3 * pt + 1], cp2 = p.point_col[3 * pt + 2];
     const int rmax = max(cp0, max(cp1, cp2));
@@ -363,37 +361,40 @@ __global__ __launch_bounds__(PP_NT) void blk_pp_gather_kernel(DevProblem p, PPGa
     if (rmax < c0 || ob == oe) return;
     const int2 *range = reinterpret_cast<const int2 *>(pp.range);
     for (int i = tid; i < 3 * PP_CW; i += PP_NT) strip[i] = 0.0;
-    PPRecord r1 = pp.recs[ob];
-    int2 g1 = range[(long)ob * nch + chunk];
-    const int o1 = min(ob + 1, oe - 1);
-    PPRecord r2 = pp.recs[o1];
-    int2 g2 = range[(long)o1 * nch + chunk];
-    PPData cur, nxt;
-    double apc[6], apn[6];
-    pp_load(cur, p, r1, pp.ipcol, rowsA, g1.x + tid, g1.y);
-    pp_load_row(apc, p, r1, rowsA, sigma2);
     __syncthreads();
-    for (int o = ob; o < oe; o++) {
-        const int o2 = min(o + 2, oe - 1);
-        const PPRecord r3 = pp.recs[o2];
-        const int2 g3 = range[(long)o2 * nch + chunk];
-        if (o + 1 < oe) {
-            pp_load(nxt, p, r2, pp.ipcol, rowsA, g2.x + tid, g2.y);
-            pp_load_row(apn, p, r2, rowsA, sigma2);
-        }
-        pp_accumulate(cur, apc, strip, c0, cp0, cp1, cp2);
-        // ranges longer than the workgroup: the remaining passes without prefetch
-        for (int j = g1.x + PP_NT + tid; j < g1.y; j += PP_NT) {
-            PPData extra;
-            pp_load(extra, p, r1, pp.ipcol, rowsA, j, g1.y);
-            pp_accumulate(extra, apc, strip, c0, cp0, cp1, cp2);
-        }
-        __syncthreads();
-        cur = nxt;
+    if (ob + wave < oe) {
+        const int o0 = ob + wave;
+        PPRecord r1 = pp.recs[o0];
+        int2 g1 = range[(long)o0 * nch + chunk];
+        const int o1 = min(o0 + NW, oe - 1);
+        PPRecord r2 = pp.recs[o1];
+        int2 g2 = range[(long)o1 * nch + chunk];
+        PPData cur, nxt;
+        double apc[6], apn[6];
+        pp_load(cur, p, r1, pp.ipcol, rowsA, g1.x + lane, g1.y);
+        pp_load_row(apc, p, r1, rowsA, sigma2);
+        for (int o = o0; o < oe; o += NW) {
+            const int o2 = min(o + 2 * NW, oe - 1);
+            const PPRecord r3 = pp.recs[o2];
+            const int2 g3 = range[(long)o2 * nch + chunk];
+            if (o + NW < oe) {
+                pp_load(nxt, p, r2, pp.ipcol, rowsA, g2.x + lane, g2.y);
+                pp_load_row(apn, p, r2, rowsA, sigma2);
+            }
+            pp_accumulate(cur, apc, strip, c0, cp0, cp1, cp2);
+            // ranges longer than a wave: the remaining passes without prefetch
+            for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
+                PPData extra;
+                pp_load(extra, p, r1, pp.ipcol, rowsA, j, g1.y);
+                pp_accumulate(extra, apc, strip, c0, cp0, cp1, cp2);
+            }
+            cur = nxt;
 #pragma unroll
-        for (int a = 0; a < 6; a++) apc[a] = apn[a];
-        r1 = r2; g1 = g2; r2 = r3; g2 = g3;
+            for (int a = 0; a < 6; a++) apc[a] = apn[a];
+            r1 = r2; g1 = g2; r2 = r3; g2 = g3;
+        }
     }
+    __syncthreads();
     const int cps[3] = {cp0, cp1, cp2};
 #pragma unroll
     for (int a = 0; a < 3; a++) {

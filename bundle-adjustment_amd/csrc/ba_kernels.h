@@ -43,7 +43,14 @@ struct PPRecord {          // one (object point, image block) incidence, 32 byte
     int64_t poff;               // offset of the block's Dinv in blk_w
     int64_t pad2;
 };
-constexpr int PP_CW = 1664;   // columns of one LDS strip of the point x point gather (3 rows x PP_CW doubles = 39 KB)
+#ifndef JAICOV_PP_CW
+#define JAICOV_PP_CW 1664
+#endif
+#ifndef JAICOV_PP_NT
+#define JAICOV_PP_NT 256
+#endif
+constexpr int PP_CW = JAICOV_PP_CW;   // columns of one LDS strip of the point x point gather (3 rows x PP_CW doubles = 39 KB)
+constexpr int PP_NT = JAICOV_PP_NT;   // threads per workgroup of the gather
 struct PPGather {
     const int32_t *pt_ip_begin = nullptr;   // [n_points+1] CSR over recs
     const PPRecord *recs = nullptr;         // image order within a point

@@ -94,27 +94,37 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
             }
     }
     __syncthreads();
-    // U[row][k] = sigma2 * sum_j T_e[row][j] Linv[k][j] ; G[k][c] += U[row][k] * Ar[row][c]  (c: io 0..2, dist 3.., w last)
-    const int ncr = kc - 6;      // reduced shared columns (io + dist)
+    // U[row][k] = sigma2 * sum_j T_e[row][j] Linv[k][j]
     for (int row = tid; row < m; row += 256) {
-        const int o = row >> 1, r = row & 1;
         const double *t = T + ((long)2 * ipb + row) * KC_LD;
-        double u[6];
+        double *uo = Ubuf + ((long)2 * ipb + row) * 8;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j <= k; j++) s += t[3 + j] * Linv[6 * k + j];
-            u[k] = sigma2 * s;
+            uo[k] = sigma2 * s;
         }
-        double *uo = Ubuf + ((long)2 * ipb + row) * 8;
-#pragma unroll
-        for (int k = 0; k < 6; k++) uo[k] = u[k];
-        for (int c = 0; c <= ncr; c++) {
+    }
+    __threadfence_block();
+    __syncthreads();
+    // G[k][c] = sum_rows U[row][k] * Ar[row][c]  (c: io 0..2, dist 3.., w last).  Thread = (column c, one of 8 row
+    // groups): six private sums, then one LDS add per thread (two lanes of a wave share an address, not sixty-four).
+    const int ncr = kc - 6;      // reduced shared columns (io + dist)
+    {
+        const int c = tid & 31, rs = tid >> 5;
+        if (c <= ncr) {
             const int cs = c < 3 ? c : c + 6;     // shared column index of reduced column c
-            const double a = c < ncr ? rowsA[(long)(2 * schur_shared_local(cs) + r) * S + ipb + o] : rowsW[(long)r * S + ipb + o];
+            const double *acol = c < ncr ? rowsA + (long)(2 * schur_shared_local(cs)) * S + ipb : rowsW + ipb;
+            double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int row = rs; row < m; row += 8) {
+                const double a = acol[(long)(row & 1) * S + (row >> 1)];
+                const double *u = Ubuf + ((long)2 * ipb + row) * 8;
 #pragma unroll
-            for (int k = 0; k < 6; k++) atomicAdd(&Gs[k * SCHUR_GLD + c], u[k] * a);
+                for (int k = 0; k < 6; k++) acc[k] += u[k] * a;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; k++) atomicAdd(&Gs[k * SCHUR_GLD + c], acc[k]);
         }
     }
     __syncthreads();
