@@ -18,7 +18,9 @@ constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry
 
 struct DenseSolver {
     hipStream_t stream = nullptr;
-    int n = 0;                 // padded order, multiple of 128
+    int n = 0;                 // rows of the storage, multiple of 128: nfact, plus 128 right-hand-side rows if `aug`
+    int nfact = 0;             // padded order of the matrix that is factorised
+    bool aug = false;          // right-hand sides are carried through the factorisation as rows nfact.. of L
     long ld = 0;
     int nbo = 512;             // outer panel width of the factorisation (multiple of 128)
     bool lookahead = true;     // factor panel s+1 on `pstream` while the rest of trailing update s runs
@@ -44,13 +46,13 @@ struct DenseSolver {
     double stat_launches = 0, stat_ms = 0, stat_flops = 0;
     void prof_collect();                 // call after the stream has been synchronised
 
-    hipError_t init(hipStream_t s, int n_padded, bool with_inverse);
+    hipError_t init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows = false);
+    double *rhs_row(int q) const { return L + (long)(nfact + q) * ld; }   // row q of the right-hand sides / of Z = Y L^-T
     void release();
     hipError_t panel(hipStream_t st, int K0, int K1);
     hipError_t timed_gemm(hipStream_t st, const GemmArgs &u, double flops);
     hipError_t potrf();                                     // L <- chol(L); info via fetch_info()
-    hipError_t backsolve(const double *Y, double *Ywork, double *X, int nrhs);   // solves L' X = Y, rows are vectors
-    hipError_t forwardsolve(double *Ywork, double *Z, int nrhs);   // solves L Z = Y (rows are vectors; Ywork is clobbered)
+    hipError_t backsolve_aug(double *X, long xs, int nrhs);  // L' X = Z, Z = the rhs rows after potrf(); X rows have stride xs
     hipError_t trtri();                                     // W <- L^-1
     hipError_t lauum();                                     // Q <- W' W (lower tiles)
     hipError_t symmetrize(double *M);                       // copy lower -> upper

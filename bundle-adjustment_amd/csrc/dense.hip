@@ -212,145 +212,133 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// substitution steps (nrhs <= 8 vectors stored as rows, length n).  One launch per 128-block; every launch streams
-// one block row / block column of L exactly once (128 KB per workgroup, coalesced), the workgroup that finishes the
-// NEXT diagonal block also applies its inverse, so the chain carries no redundant work.
+// substitution (nrhs <= 8 right-hand sides).
+// Forward: none.  The right-hand sides ride through the factorisation as 128 extra rows below the matrix
+// (DenseSolver::aug): chol([[M, Y'], [Y, *]]) = [[L, 0], [Z, *]] with Z = Y L^-T, i.e. row q of Z is (L^-1 y_q)'.
+// Backward: L' X = Z in ONE launch.  Workgroup b owns block column k = nb-1-b: it streams the blocks L[j][k], j > k,
+// (double-buffered in registers) and subtracts L[j][k]' x_j as soon as the owner of column j has published x_j, then
+// applies the inverse of its diagonal block and publishes x_k.  The data are their own flags: X is preset to an
+// all-ones bit pattern, results are written and polled with relaxed agent-scope atomics (coherent across the XCDs,
+// no cache-wide fences), a value counts as published once it differs from the pattern.  A workgroup only ever waits
+// for workgroups with a smaller index, which the dispatcher starts first: the chain cannot deadlock whatever the
+// residency; a bounded spin turns a lost predecessor into NaNs instead of a hang.  Per chain link the latency is one
+// store-to-load round trip + one 128x128 block instead of a kernel launch.
 // ---------------------------------------------------------------------------------------------------------------
-// x = invL' y (TRANS) or invL y for one diagonal block; invd is 128x128 row-major lower.  256 threads.
-// v: [nrhs][128] in LDS (input), out: [nrhs][128] in LDS; tile: 128*DP scratch.
-template <bool TRANS>
-__device__ __forceinline__ void apply_diag_inverse(const double *__restrict__ invd, const double (*v)[128],
-                                                   double (*out)[128], double *tile, int nrhs) {
+constexpr unsigned long long BS_UNSET = ~0ull;
+constexpr int BS_SPIN_MAX = 1 << 22;
+
+__global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__restrict__ L, long ld,
+                                                              const double *__restrict__ invd, const double *__restrict__ Z,
+                                                              long zs, double *X, long xs, int nb, int nrhs) {
+    __shared__ __attribute__((aligned(16))) double xj[2][128][DENSE_MAX_RHS];     // x_j (then v_k), [row][rhs]
+    __shared__ __attribute__((aligned(16))) double red[4][128][DENSE_MAX_RHS];    // partial sums
     const int tid = threadIdx.x;
-    // coalesced load of the block into LDS
-#pragma unroll 4
-    for (int i = 0; i < 32; i++) {
-        const int r = (tid >> 6) + 4 * i, c = 2 * (tid & 63);
-        const d2_t x = *reinterpret_cast<const d2_t *>(invd + r * 128 + c);
-        tile[r * DP + c] = x.x;
-        tile[r * DP + c + 1] = x.y;
+    const int k = nb - 1 - (int)blockIdx.x;
+    const int c2 = tid & 63, qd = tid >> 6;        // block phase: columns 2*c2, 2*c2+1; rows 32*qd .. 32*qd+31
+    const int di = tid & 127, dh = tid >> 7;       // diagonal phase: output row di, half dh of the sum
+    const int sr = tid & 127, sq = tid >> 7;       // staging: row sr, right-hand sides sq, sq+2, sq+4, sq+6
+    // inverse of the diagonal block and the right-hand side of this block, fetched ahead
+    double dinv[64], zk[4];
+    {
+        const double *w = invd + (long)k * 16384 + (long)(64 * dh) * 128 + di;
+#pragma unroll
+        for (int r = 0; r < 64; r++) dinv[r] = w[(long)r * 128];
+#pragma unroll
+        for (int i = 0; i < 4; i++) zk[i] = sq + 2 * i < nrhs ? Z[(long)(sq + 2 * i) * zs + k * 128 + sr] : 0.0;
     }
-    __syncthreads();
-    const int t = tid & 127, h = tid >> 7;
-    for (int q = h; q < nrhs; q += 2) {
-        double s = 0.0;
-        if (TRANS) {
-            for (int r = t; r < 128; r++) s += tile[r * DP + t] * v[q][r];
-        } else {
-            for (int c = 0; c <= t; c++) s += tile[t * DP + c] * v[q][c];
+    double acc[2][DENSE_MAX_RHS];
+#pragma unroll
+    for (int q = 0; q < DENSE_MAX_RHS; q++) acc[0][q] = acc[1][q] = 0.0;
+    d2_t blk[32], nblk[32];
+    int j = nb - 1;
+    if (j > k) {
+        const double *lp = L + (long)(j * 128 + 32 * qd) * ld + k * 128 + 2 * c2;
+#pragma unroll
+        for (int r = 0; r < 32; r++) blk[r] = *reinterpret_cast<const d2_t *>(lp + (long)r * ld);
+    }
+    for (; j > k; --j) {
+        if (j - 1 > k) {
+            const double *lp = L + (long)((j - 1) * 128 + 32 * qd) * ld + k * 128 + 2 * c2;
+#pragma unroll
+            for (int r = 0; r < 32; r++) nblk[r] = *reinterpret_cast<const d2_t *>(lp + (long)r * ld);
         }
-        out[q][t] = s;
-    }
-    __syncthreads();
-}
-
-// backward, step k (k = nb-1 .. 1): y_b -= L[k][b]' x_k for b < k; the workgroup b = k-1 then sets x_{k-1}.
-// X block k must already hold x_k.  grid = k, block = 256.
-__global__ __launch_bounds__(256) void backsub_step_kernel(const double *__restrict__ L, long ld,
-                                                           const double *__restrict__ invd, double *Y, double *X, int n,
-                                                           int k, int nrhs) {
-    __shared__ double xk[DENSE_MAX_RHS][128];
-    __shared__ double part[DENSE_MAX_RHS][128];
-    __shared__ double tile[128 * DP];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int c = tid & 127, h = tid >> 7;
-    if (tid < 128)
-        for (int q = 0; q < nrhs; q++) xk[q][tid] = X[(long)q * n + k * 128 + tid];
-    __syncthreads();
-    double acc[DENSE_MAX_RHS];
+        {   // wait for x_j: every thread polls the (up to four) values it stages
+            unsigned long long b[4];
+            const unsigned long long *xp = reinterpret_cast<const unsigned long long *>(X) + j * 128 + sr;
+            int spin = 0;
+            bool ready;
+            do {
+                ready = true;
 #pragma unroll
-    for (int q = 0; q < DENSE_MAX_RHS; q++) acc[q] = 0.0;
-    const double *lp = L + (long)(k * 128 + 64 * h) * ld + b * 128 + c;
-    for (int r0 = 0; r0 < 64; r0 += 16) {
-        double l[16];
+                for (int i = 0; i < 4; i++) {
+                    b[i] = 0;
+                    if (sq + 2 * i < nrhs) {
+                        b[i] = __hip_atomic_load(xp + (long)(sq + 2 * i) * xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ready = ready && b[i] != BS_UNSET;
+                    }
+                }
+                if (!ready) __builtin_amdgcn_s_sleep(2);
+            } while (!ready && ++spin < BS_SPIN_MAX);
 #pragma unroll
-        for (int i = 0; i < 16; i++) l[i] = lp[(long)(r0 + i) * ld];
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-#pragma unroll
-            for (int q = 0; q < DENSE_MAX_RHS; q++)
-                if (q < nrhs) acc[q] += l[i] * xk[q][64 * h + r0 + i];
-    }
-    if (h == 1)
-        for (int q = 0; q < nrhs; q++) part[q][c] = acc[q];
-    __syncthreads();
-    if (h == 0)
-        for (int q = 0; q < nrhs; q++) {
-            const double v = Y[(long)q * n + b * 128 + c] - (acc[q] + part[q][c]);
-            Y[(long)q * n + b * 128 + c] = v;
-            part[q][c] = v;
+            for (int i = 0; i < 4; i++) xj[j & 1][sr][sq + 2 * i] = __longlong_as_double((long long)b[i]);
         }
-    if (b == k - 1) {   // block-uniform
         __syncthreads();
-        apply_diag_inverse<true>(invd + (long)(k - 1) * 16384, part, xk, tile, nrhs);
-        if (tid < 128)
-            for (int q = 0; q < nrhs; q++) X[(long)q * n + (k - 1) * 128 + tid] = xk[q][tid];
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const d4_t x0 = *reinterpret_cast<const d4_t *>(&xj[j & 1][32 * qd + r][0]);
+            const d4_t x1 = *reinterpret_cast<const d4_t *>(&xj[j & 1][32 * qd + r][4]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                acc[0][q] += blk[r].x * x0[q];
+                acc[1][q] += blk[r].y * x0[q];
+                acc[0][4 + q] += blk[r].x * x1[q];
+                acc[1][4 + q] += blk[r].y * x1[q];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 32; r++) blk[r] = nblk[r];
     }
-}
-
-// forward, step k (k = 0 .. nb-2): y_b -= L[b][k] z_k for b > k; the workgroup b = k+1 then sets z_{k+1}.
-// Z block k must already hold z_k.  grid = nb-1-k, block = 256.
-__global__ __launch_bounds__(256) void fwdsub_step_kernel(const double *__restrict__ L, long ld,
-                                                          const double *__restrict__ invd, double *Y, double *Z, int n,
-                                                          int k, int nrhs) {
-    __shared__ double zk[DENSE_MAX_RHS][128];
-    __shared__ double part[DENSE_MAX_RHS][128];
-    __shared__ double tile[128 * DP];
-    const int tid = threadIdx.x, b = k + 1 + blockIdx.x;
-    if (tid < 128)
-        for (int q = 0; q < nrhs; q++) zk[q][tid] = Z[(long)q * n + k * 128 + tid];
-    {   // coalesced load of the tile L[b][k] into LDS: one row (1 KB) per wave instruction
-        const double *lp = L + (long)(b * 128) * ld + k * 128;
-#pragma unroll 8
-        for (int i = 0; i < 32; i++) {
-            const int r = (tid >> 6) + 4 * i, cc = 2 * (tid & 63);
-            const d2_t x = *reinterpret_cast<const d2_t *>(lp + (long)r * ld + cc);
-            tile[r * DP + cc] = x.x;
-            tile[r * DP + cc + 1] = x.y;
+#pragma unroll
+    for (int q = 0; q < DENSE_MAX_RHS; q++) {
+        red[qd][2 * c2][q] = acc[0][q];
+        red[qd][2 * c2 + 1][q] = acc[1][q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int q = sq + 2 * i;
+        xj[0][sr][q] = zk[i] - (red[0][sr][q] + red[1][sr][q] + red[2][sr][q] + red[3][sr][q]);
+    }
+    __syncthreads();
+    // x_k[di] = sum_r W[r][di] v[r]
+    double out[DENSE_MAX_RHS];
+#pragma unroll
+    for (int q = 0; q < DENSE_MAX_RHS; q++) out[q] = 0.0;
+#pragma unroll
+    for (int r = 0; r < 64; r++) {
+        const d4_t v0 = *reinterpret_cast<const d4_t *>(&xj[0][64 * dh + r][0]);
+        const d4_t v1 = *reinterpret_cast<const d4_t *>(&xj[0][64 * dh + r][4]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            out[q] += dinv[r] * v0[q];
+            out[4 + q] += dinv[r] * v1[q];
         }
     }
-    __syncthreads();
-    const int r = tid & 127, h = tid >> 7;
-    double acc[DENSE_MAX_RHS];
+    if (dh == 1) {
 #pragma unroll
-    for (int q = 0; q < DENSE_MAX_RHS; q++) acc[q] = 0.0;
-    for (int cc = 64 * h; cc < 64 * h + 64; cc++) {
-        const double l = tile[r * DP + cc];
-#pragma unroll
-        for (int q = 0; q < DENSE_MAX_RHS; q++)
-            if (q < nrhs) acc[q] += l * zk[q][cc];
+        for (int q = 0; q < DENSE_MAX_RHS; q++) red[0][di][q] = out[q];
     }
-    if (h == 1)
-        for (int q = 0; q < nrhs; q++) part[q][r] = acc[q];
     __syncthreads();
-    if (h == 0)
-        for (int q = 0; q < nrhs; q++) {
-            const double v = Y[(long)q * n + b * 128 + r] - (acc[q] + part[q][r]);
-            Y[(long)q * n + b * 128 + r] = v;
-            part[q][r] = v;
+    if (dh == 0) {
+        unsigned long long *xp = reinterpret_cast<unsigned long long *>(X) + k * 128 + di;
+#pragma unroll
+        for (int q = 0; q < DENSE_MAX_RHS; q++) {
+            if (q >= nrhs) break;
+            unsigned long long bits = (unsigned long long)__double_as_longlong(out[q] + red[0][di][q]);
+            if (bits == BS_UNSET) bits = 0x7FF8000000000000ull;
+            __hip_atomic_store(xp + (long)q * xs, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    if (b == k + 1) {
-        __syncthreads();
-        apply_diag_inverse<false>(invd + (long)(k + 1) * 16384, part, zk, tile, nrhs);
-        if (tid < 128)
-            for (int q = 0; q < nrhs; q++) Z[(long)q * n + (k + 1) * 128 + tid] = zk[q][tid];
     }
-}
-
-// first block of a chain: out_k = invL_kk(') y_k.  grid = 1, block = 256
-template <bool TRANS>
-__global__ __launch_bounds__(256) void diag_apply_kernel(const double *__restrict__ invd_k, const double *Y, double *X,
-                                                         int n, int k, int nrhs) {
-    __shared__ double v[DENSE_MAX_RHS][128];
-    __shared__ double o[DENSE_MAX_RHS][128];
-    __shared__ double tile[128 * DP];
-    const int tid = threadIdx.x;
-    if (tid < 128)
-        for (int q = 0; q < nrhs; q++) v[q][tid] = Y[(long)q * n + k * 128 + tid];
-    __syncthreads();
-    apply_diag_inverse<TRANS>(invd_k, v, o, tile, nrhs);
-    if (tid < 128)
-        for (int q = 0; q < nrhs; q++) X[(long)q * n + k * 128 + tid] = o[q][tid];
 }
 
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
@@ -381,23 +369,26 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double *M, long ld, int
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse) {
+hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows) {
     stream = s;
-    n = n_padded;
-    ld = n_padded;
+    aug = with_rhs_rows;
+    nfact = n_padded;
+    n = n_padded + (aug ? 128 : 0);
+    ld = n;
     owns = true;
     const size_t sq = (size_t)n * ld * sizeof(double);
     HIPCHK(hipMalloc(&L, sq));
-    HIPCHK(hipMalloc(&invd, (size_t)(n / 128) * 16384 * sizeof(double)));
-    HIPCHK(hipMemset(invd, 0, (size_t)(n / 128) * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&invd, (size_t)(nfact / 128) * 16384 * sizeof(double)));
+    HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
+
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, greatest));
         // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask enables CU i/8 of every XCD):
         // the trailing updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.
-        if (n >= 2048 && !getenv("JAICOV_NO_CUMASK")) {
+        if (nfact >= 2048 && !getenv("JAICOV_NO_CUMASK")) {
             uint32_t upd[8], dia[8];
             for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
             upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u;
@@ -414,7 +405,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse) {
     if (with_inverse) {
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
-        const size_t half = (size_t)(n / 2 + 128);
+        const size_t half = (size_t)(nfact / 2 + 128);
         T_elems = half * half;
         HIPCHK(hipMalloc(&T, T_elems * sizeof(double)));
     }
@@ -516,7 +507,7 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
 }
 
 hipError_t DenseSolver::potrf() {
-    const int nb = n / 128;
+    const int nb = nfact / 128;   // diagonal blocks; rows run to n (the right-hand-side rows below the matrix included)
     if (const char *e = getenv("JAICOV_NBO")) nbo = atoi(e);
     const int bo = nbo / 128 > 0 ? nbo / 128 : 1;
     const int S = (nb + bo - 1) / bo;
@@ -558,7 +549,7 @@ hipError_t DenseSolver::potrf() {
         }
         // (b) the rest of the trailing matrix: rows, cols >= K2 (lower tiles)
         const int rows = n - K2 * 128;
-        if (rows > 0) {
+        if (rows > 0 && K2 < nb) {
             GemmArgs u{};
             u.A = L + (long)(K2 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
             u.C = L + (long)(K2 * 128) * ld + K2 * 128; u.ldc = ld;
@@ -578,21 +569,11 @@ hipError_t DenseSolver::potrf() {
     return hipGetLastError();
 }
 
-hipError_t DenseSolver::forwardsolve(double *Ywork, double *Z, int nrhs) {
-    const int nb = n / 128;
-    hipLaunchKernelGGL(diag_apply_kernel<false>, dim3(1), dim3(256), 0, stream, invd, Ywork, Z, n, 0, nrhs);
-    for (int k = 0; k + 1 < nb; k++)
-        hipLaunchKernelGGL(fwdsub_step_kernel, dim3(nb - 1 - k), dim3(256), 0, stream, L, ld, invd, Ywork, Z, n, k, nrhs);
-    return hipGetLastError();
-}
-
-hipError_t DenseSolver::backsolve(const double *Y, double *Ywork, double *X, int nrhs) {
-    const int nb = n / 128;
-    HIPCHK(hipMemcpyAsync(Ywork, Y, (size_t)nrhs * n * sizeof(double), hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(diag_apply_kernel<true>, dim3(1), dim3(256), 0, stream, invd + (long)(nb - 1) * 16384, Ywork, X, n,
-                       nb - 1, nrhs);
-    for (int k = nb - 1; k >= 1; k--)
-        hipLaunchKernelGGL(backsub_step_kernel, dim3(k), dim3(256), 0, stream, L, ld, invd, Ywork, X, n, k, nrhs);
+hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
+    if (!aug || nrhs < 1 || nrhs > DENSE_MAX_RHS) return hipErrorInvalidValue;
+    const int nb = nfact / 128;
+    HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nrhs * xs * sizeof(double), stream));   // "not yet published"
+    hipLaunchKernelGGL(backsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
     return hipGetLastError();
 }
 
@@ -617,7 +598,7 @@ static hipError_t trtri_rec(DenseSolver &s, int lo, int hi) {
 }
 
 hipError_t DenseSolver::trtri() {
-    const int nb = n / 128;
+    const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(W, 0, (size_t)n * ld * sizeof(double), stream));
     hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(nb), dim3(256), 0, stream, invd, W, ld);
     return trtri_rec(*this, 0, nb);
@@ -626,12 +607,12 @@ hipError_t DenseSolver::trtri() {
 hipError_t DenseSolver::lauum() {
     GemmArgs g{};
     g.A = W; g.lda = ld; g.B = W; g.ldb = ld; g.C = Q; g.ldc = ld;
-    g.M = n; g.N = n; g.K = n; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.kmode = KMODE_GE_ROW;
+    g.M = nfact; g.N = nfact; g.K = nfact; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 1; g.kmode = KMODE_GE_ROW;
     return gemm_f64(stream, LAY_XC, LAY_XC, g);
 }
 
 hipError_t DenseSolver::symmetrize(double *M) {
-    const int nt = n / 32;
+    const int nt = nfact / 32;
     hipLaunchKernelGGL(symmetrize_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, stream, M, ld, nt);
     return hipGetLastError();
 }

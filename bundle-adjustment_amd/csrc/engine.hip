@@ -589,7 +589,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_F, true))) return rc;
     if ((rc = dalloc(e, (size_t)64, &e->d_E, true))) return rc;
     if ((rc = dalloc(e, (size_t)1, &e->d_omega, true))) return rc;
-    HIPE(e, e->solver.init(e->stream, e->Upad, false));
+    HIPE(e, e->solver.init(e->stream, e->Upad, false, true));
     // ---- EO pre-elimination is possible when every image point sits in an image block, the EO columns are the
     //      trailing columns e0 + 6*image + k, and no directly observed parameter is an EO parameter ------------------
     {
@@ -849,12 +849,12 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     const int U = schur ? e->e0 : e->U, d = e->d, nrhs = d + 1;
     const int Upad = e->Upad;                      // leading dimension of N, V, B and the rhs/solution vectors
     if (schur && !e->solverS_ready) {
-        HIPE(e, e->solverS.init(e->stream, ((e->e0 + 127) / 128) * 128, false));
+        HIPE(e, e->solverS.init(e->stream, ((e->e0 + 127) / 128) * 128, false, true));
         e->solverS_ready = true;
     }
     DenseSolver &slv = schur ? e->solverS : e->solver;
     slv.profile = e->solver.profile;
-    const int Up = slv.n;                          // padded order of the factorised system
+    const int Up = slv.nfact;                      // padded order of the factorised system
     const long ld = slv.ld;
     if (schur) {
         int hinfo = 0;
@@ -863,7 +863,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
     }
     if (invert && !e->solver_has_inverse) {
-        const size_t sq = (size_t)Upad * Upad * sizeof(double);
+        const size_t sq = (size_t)e->solver.n * e->solver.ld * sizeof(double);
         HIPE(e, hipMalloc(&e->solver.W, sq));
         HIPE(e, hipMalloc(&e->solver.Q, sq));
         const size_t half = (size_t)(Upad / 2 + 128);
@@ -891,17 +891,17 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     HIPE(e, hipEventRecord(e->ev[4], e->stream));
     hipLaunchKernelGGL(scale_copy_kernel, dim3((Up + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
                        Up, d, e->d_V, e->d_B, Upad);
-    // right-hand sides: row 0 = V n, rows 1..d = Bh
-    const int vs = Up;   // stride between the rhs / solution vectors (the solver's order)
-    hipLaunchKernelGGL(scale_vec_kernel, dim3((Up + 255) / 256), dim3(256), 0, e->stream, e->d_n, e->d_V, e->d_Y, U, Up, d);
+    // right-hand sides: row 0 = V n, rows 1..d = Bh.  They are the extra rows below the matrix, so the factorisation
+    // itself carries out the forward substitution (dense.hip).
+    const int vs = Up;   // stride between the solution vectors (the solver's order)
+    HIPE(e, hipMemsetAsync(slv.rhs_row(0), 0, (size_t)128 * ld * sizeof(double), e->stream));
+    hipLaunchKernelGGL(scale_vec_kernel, dim3((Up + 255) / 256), dim3(256), 0, e->stream, e->d_n, e->d_V, slv.rhs_row(0), U, Up, d);
     if (d > 0)
-        HIPE(e, hipMemcpy2DAsync(e->d_Y + vs, (size_t)vs * sizeof(double), e->d_B, (size_t)Upad * sizeof(double),
+        HIPE(e, hipMemcpy2DAsync(slv.rhs_row(1), (size_t)ld * sizeof(double), e->d_B, (size_t)Upad * sizeof(double),
                                  (size_t)Up * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, e->stream));
     HIPE(e, slv.potrf());
     HIPE(e, hipEventRecord(e->ev[5], e->stream));
-    HIPE(e, hipMemcpyAsync(e->d_Yw, e->d_Y, (size_t)nrhs * vs * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    HIPE(e, slv.forwardsolve(e->d_Yw, e->d_X, nrhs));       // X <- L^-1 Y
-    HIPE(e, slv.backsolve(e->d_X, e->d_Yw, e->d_G, nrhs));  // G <- L^-T X   (row 0: y~, rows 1..d: G^)
+    HIPE(e, slv.backsolve_aug(e->d_G, vs, nrhs));           // G <- L^-T (L^-1 Y)   (row 0: y~, rows 1..d: G^)
     HIPE(e, hipEventRecord(e->ev[6], e->stream));
     std::vector<double> X((size_t)nrhs * vs);
     HIPE(e, hipMemcpyAsync(X.data(), e->d_G, X.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1071,7 +1071,7 @@ extern "C" int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_
     HIPE(e, hipSetDevice(e->device));
     double *d_ap = nullptr;
     HIPE(e, hipMalloc(&d_ap, std::max<size_t>(len, 1) * sizeof(double)));
-    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, e->solver.Q, (long)e->Upad, U, d_ap);
+    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, e->solver.Q, e->solver.ld, U, d_ap);
     hipError_t he = hipMemcpyAsync(Q_packed, d_ap, len * sizeof(double), hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     hipFree(d_ap);
@@ -1091,7 +1091,7 @@ extern "C" int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx,
     hipError_t he = hipMalloc(&d_out, (size_t)k * k * sizeof(double));
     if (he == hipSuccess) he = hipMemcpyAsync(d_idx, idx, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) {
-        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, e->solver.Q, (long)e->Upad, d_idx, k, d_out);
+        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, e->solver.Q, e->solver.ld, d_idx, k, d_out);
         he = hipMemcpyAsync(out, d_out, (size_t)k * k * sizeof(double), hipMemcpyDeviceToHost, e->stream);
     }
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -1231,7 +1231,7 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     do {
-        if (ds.init(s, np, invert != 0) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
+        if (ds.init(s, np, invert != 0, true) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
         if (hipMalloc(&d_ap, len * sizeof(double)) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
         hipMalloc(&d_Y, (size_t)DENSE_MAX_RHS * np * sizeof(double));
         hipMalloc(&d_Yw, (size_t)DENSE_MAX_RHS * np * sizeof(double));
@@ -1240,14 +1240,11 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
         // identity padding, then unpack the lower triangle
         hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np, (const int32_t *)nullptr);
         hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, d_ap, ds.ld, n, ds.L);
-        hipMemsetAsync(d_Yw, 0, (size_t)DENSE_MAX_RHS * np * sizeof(double), s);
-        for (int q = 0; q < nrhs; q++) hipMemcpyAsync(d_Yw + (size_t)q * np, b + (size_t)q * n, n * sizeof(double), hipMemcpyHostToDevice, s);
+        hipMemsetAsync(ds.rhs_row(0), 0, (size_t)128 * ds.ld * sizeof(double), s);
+        for (int q = 0; q < nrhs; q++) hipMemcpyAsync(ds.rhs_row(q), b + (size_t)q * n, n * sizeof(double), hipMemcpyHostToDevice, s);
         hipEventRecord(e0, s);
         if (ds.potrf() != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
-        if (nrhs > 0) {
-            ds.forwardsolve(d_Yw, d_X, nrhs);
-            ds.backsolve(d_X, d_Yw, d_Y, nrhs);
-        }
+        if (nrhs > 0) ds.backsolve_aug(d_Y, np, nrhs);
         if (invert) {
             ds.trtri();
             ds.lauum();
