@@ -58,6 +58,13 @@ __global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int
     V[c] = v;
 }
 
+// zero the lower triangle (row r: columns 0 .. r, rounded up to 4) of the leading `rows` rows; grid (ceil(rows/1024), rows)
+__global__ __launch_bounds__(256) void zero_lower_kernel(double *__restrict__ N, long ld, int rows) {
+    const int r = blockIdx.y, c = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (c > r) return;
+    *reinterpret_cast<d4_t *>(N + (long)r * ld + c) = (d4_t){0.0, 0.0, 0.0, 0.0};
+}
+
 // M = V N V + Bh' Bh on the unknown block (lower part), identity on border and padding.  Bh: [d][bstride]
 __global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restrict__ N, long ldN, double *__restrict__ M,
                                                          long ld, int U, int Upad, int d, const double *__restrict__ V,
@@ -678,9 +685,13 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     int rc = ensure_rows(e);
     if (rc) return rc;
     HIPE(e, hipEventRecord(e->ev[1], e->stream));
-    HIPE(e, hipMemsetAsync(e->d_N, 0, (sq + e->Upad) * sizeof(double), e->stream));
-    HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     e->schur_active = e->schur_ok && !e->want_inverse_next;
+    {   // only the lower triangle of N is ever written or read (nadd, pack, scale_copy); the reduced system has e0 rows
+        const int rows = e->schur_active ? std::min(e->Upad, ((e->e0 + 127) / 128) * 128) : e->Upad;
+        hipLaunchKernelGGL(zero_lower_kernel, dim3((rows + 1023) / 1024, rows), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, rows);
+        HIPE(e, hipMemsetAsync(e->d_N + sq, 0, (size_t)e->Upad * sizeof(double), e->stream));
+    }
+    HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     SchurBufs sb = e->sb;
     if (!e->schur_active) sb.Pp = nullptr;
     sb.lambda = e->lambda_acc;

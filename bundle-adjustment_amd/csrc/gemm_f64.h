@@ -144,7 +144,9 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
     };
 
     // accumulators start from (beta/alpha)*C, so the epilogue is a pure store (alpha*acc): the C tile is fetched while
-    // the first operand tiles are still in flight instead of as a dependent read-modify-write at the end.
+    // the first operand tiles (requested first) are still in flight instead of as a dependent read-modify-write at the end.
+    const int nk = (kend - kbeg) / GEMM_BK;
+    if (nk > 0) gload();
     const double alpha = g.alpha, beta = g.beta;
     double *cbase = C + (m0 + WTM * wr + (lane >> 4)) * g.ldc + n0 + WTN * wc + (lane & 15);
     d4_t acc[MTM][MTN];
@@ -163,10 +165,8 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
             for (int j = 0; j < MTN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
 
-    const int nk = (kend - kbeg) / GEMM_BK;
     if (g.trace) t_loop0 = wall_clock64();
     if (nk > 0) {
-        gload();
         lstore(0);
         __syncthreads();
         const int fa = (lane >> 4) * LDA_S + WTM * wr + (lane & 15);
