@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <map>
 #include <vector>
 
 namespace jaicov {
@@ -30,6 +31,8 @@ struct DenseSolver {
     std::vector<hipEvent_t> sync_ev;
     size_t ev_used = 0;
     hipEvent_t next_event();
+    std::map<int, std::pair<int2 *, int>> tile_maps;   // XCD-aware tile order of the trailing update, by tile rows
+    bool xcd_maps = true;
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse

@@ -415,6 +415,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
 void DenseSolver::release() {
     if (!owns) return;
     hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(T);
+    for (auto &kv : tile_maps) hipFree(kv.second.first);
+    tile_maps.clear();
     for (auto ev : prof_ev) hipEventDestroy(ev);
     prof_ev.clear();
     for (auto ev : sync_ev) hipEventDestroy(ev);
@@ -509,10 +511,17 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
 hipError_t DenseSolver::potrf() {
     const int nb = nfact / 128;   // diagonal blocks; rows run to n (the right-hand-side rows below the matrix included)
     if (const char *e = getenv("JAICOV_NBO")) nbo = atoi(e);
+    // Panel width: wide panels (K = 2 nbo) make the trailing update more efficient while it dominates (many rows left),
+    // narrow ones shorten the panel chain once that is the critical path.
+    static const int big_rows = getenv("JAICOV_NBO_BIG_ROWS") ? atoi(getenv("JAICOV_NBO_BIG_ROWS")) : 1 << 30;
+    static const int small_rows = getenv("JAICOV_NBO_SMALL_ROWS") ? atoi(getenv("JAICOV_NBO_SMALL_ROWS")) : 0;
     const int bo = nbo / 128 > 0 ? nbo / 128 : 1;
-    const int S = (nb + bo - 1) / bo;
+    auto width = [&](int K) {
+        const int rows = n - K * 128;
+        return rows > big_rows ? 2 * bo : (rows > small_rows ? bo : (bo > 1 ? bo / 2 : 1));
+    };
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
-    const bool la = lookahead && pstream != nullptr && S > 1;
+    const bool la = lookahead && pstream != nullptr && nb > bo;
     ev_used = 0;
     hipStream_t sp = la ? pstream : stream;                 // panel GEMMs
     hipStream_t su = la && ustream ? ustream : stream;      // trailing updates (all CUs but the reserved ones)
@@ -522,13 +531,12 @@ hipError_t DenseSolver::potrf() {
         HIPCHK(hipStreamWaitEvent(sp, e_start, 0));
         if (su != stream) HIPCHK(hipStreamWaitEvent(su, e_start, 0));
     }
-    HIPCHK(panel(sp, 0, bo < nb ? bo : nb));
+    int K0 = 0, K1 = width(0) < nb ? width(0) : nb;
+    HIPCHK(panel(sp, 0, K1));
     hipEvent_t e_panel = next_event();
     if (la) HIPCHK(hipEventRecord(e_panel, sp));
-    for (int s = 0; s < S; s++) {
-        const int K0 = s * bo, K1 = (K0 + bo < nb) ? K0 + bo : nb;
-        if (K1 >= nb) break;
-        const int K2 = (K1 + bo < nb) ? K1 + bo : nb;     // end of the next panel
+    while (K1 < nb) {
+        const int K2 = (K1 + width(K1) < nb) ? K1 + width(K1) : nb;     // end of the next panel
         if (la) HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
         const int Kw = (K1 - K0) * 128;
         // (a) columns of the next panel: rows >= K1, cols [K1,K2)
@@ -554,8 +562,24 @@ hipError_t DenseSolver::potrf() {
             u.A = L + (long)(K2 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
             u.C = L + (long)(K2 * 128) * ld + K2 * 128; u.ldc = ld;
             u.M = rows; u.N = rows; u.K = Kw; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
+            static const bool no_maps = getenv("JAICOV_NO_XCD_MAP") != nullptr;
+            if (xcd_maps && !no_maps && rows / 128 >= 24) {
+                const int T = rows / 128;
+                auto it = tile_maps.find(T);
+                if (it == tile_maps.end()) {
+                    const std::vector<int2> m = xcd_tile_map(T);
+                    int2 *d = nullptr;
+                    HIPCHK(hipMalloc(&d, m.size() * sizeof(int2)));
+                    HIPCHK(hipMemcpy(d, m.data(), m.size() * sizeof(int2), hipMemcpyHostToDevice));
+                    it = tile_maps.emplace(T, std::make_pair(d, (int)m.size())).first;
+                }
+                u.tile_map = it->second.first;
+                u.n_map = it->second.second;
+            }
             HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
         }
+        K0 = K1;
+        K1 = K2;
     }
     if (la) {   // the main stream continues only after the last panel and the last update
         hipEvent_t e1 = next_event(), e2 = next_event();

@@ -17,6 +17,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <vector>
+
 namespace jaicov {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
@@ -37,6 +40,8 @@ struct GemmArgs {
     int kmode;           // restrict the k range per tile (triangular operands), see KMODE_*
     long strideA, strideB, strideC;  // batch strides (blockIdx.y)
     long long *trace;    // debug: per workgroup {start, loop begin, loop end, end} of the 100 MHz clock + hardware id
+    const int2 *tile_map; // optional: workgroup -> (tile_row, tile_col), row < 0 = no tile (see xcd_tile_map)
+    int n_map;            // entries of tile_map = workgroups to launch
 };
 
 // TM = 128: the throughput tile described above.  TM = 64: latency variant for launches that cannot fill the chip with
@@ -55,7 +60,12 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
     const int wr = wave >> 1, wc = wave & 1;
 
     int tile_row, tile_col;
-    {
+    if (g.tile_map) {
+        const int2 rc = g.tile_map[blockIdx.x];
+        if (rc.x < 0) return;
+        tile_row = rc.x;
+        tile_col = rc.y;
+    } else {
         const int t = blockIdx.x;
         if (g.lower_only) {
             // t -> (row, col) over the lower triangle, row-major: t = row(row+1)/2 + col
@@ -210,6 +220,50 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
     }
 }
 
+// XCD-aware order of the lower-triangular tile grid (T tile rows).  Workgroups are dealt round-robin to the 8 XCDs
+// (workgroup w runs on XCD w % 8), each XCD has its own 4 MB L2 and runs ~62 tiles at a time.  The map gives every XCD
+// whole 8x8 super-tiles: the 64 tiles that are in flight together on one XCD share 8 A strips and 8 B strips and walk
+// along k in step, so a strip is fetched from HBM once per super-tile instead of once per tile.
+inline std::vector<int2> xcd_tile_map(int T) {
+    constexpr int S = 8, X = 8;
+    struct Super { int R, C, count; };
+    std::vector<Super> sup;
+    const int nS = (T + S - 1) / S;
+    for (int R = 0; R < nS; R++)
+        for (int C = 0; C <= R; C++) {
+            int cnt = 0;
+            for (int r = R * S; r < std::min(T, (R + 1) * S); r++)
+                for (int c = C * S; c < std::min(T, (C + 1) * S); c++) cnt += c <= r;
+            sup.push_back({R, C, cnt});
+        }
+    std::stable_sort(sup.begin(), sup.end(), [](const Super &a, const Super &b) { return a.count > b.count; });
+    std::vector<std::vector<int2>> lists(X);
+    for (const Super &s : sup) {
+        int best = 0;
+        for (int x = 1; x < X; x++)
+            if (lists[x].size() < lists[best].size()) best = x;
+        for (int r = s.R * S; r < std::min(T, (s.R + 1) * S); r++)
+            for (int c = s.C * S; c < std::min(T, (s.C + 1) * S); c++)
+                if (c <= r) lists[best].push_back(make_int2(r, c));
+    }
+    for (;;) {   // level the tails tile by tile: all XCDs finish within one tile of each other
+        int lo = 0, hi = 0;
+        for (int x = 1; x < X; x++) {
+            if (lists[x].size() < lists[lo].size()) lo = x;
+            if (lists[x].size() > lists[hi].size()) hi = x;
+        }
+        if (lists[hi].size() <= lists[lo].size() + 1) break;
+        lists[lo].push_back(lists[hi].back());
+        lists[hi].pop_back();
+    }
+    size_t len = 0;
+    for (auto &l : lists) len = std::max(len, l.size());
+    std::vector<int2> map(len * X, make_int2(-1, -1));
+    for (int x = 0; x < X; x++)
+        for (size_t q = 0; q < lists[x].size(); q++) map[q * X + x] = lists[x][q];
+    return map;
+}
+
 // Launches that cannot give every CU two 128-tiles (the regime in which the 128-tile runs at its rate) take the
 // 64-tile latency variant; `small_tiles` < 0 = that rule, 0 = never, 1 = always (rectangular KMODE_FULL calls only).
 constexpr int GEMM_SMALL_TILE_LIMIT = 480;
@@ -217,7 +271,7 @@ inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g,
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const int tm = g.M / 128, tn = g.N / 128;
     const int tiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
-    dim3 grid(tiles, batch), block(256);
+    dim3 grid(g.tile_map ? g.n_map : tiles, batch), block(256);
     const bool can_small = !g.lower_only && g.kmode == KMODE_FULL && alay == LAY_KC && blay == LAY_KC;
     if (can_small && (small_tiles > 0 || (small_tiles < 0 && tiles * batch < GEMM_SMALL_TILE_LIMIT))) {
         if (g.C == g.A || g.C == g.B) {   // in place (one column tile): keep the whole row of C in one workgroup

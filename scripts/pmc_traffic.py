@@ -3,31 +3,32 @@
 HBM bytes per launch of the dominant kernel (the lower-triangular Cholesky trailing update, gemm_f64_kernel<KC,KC> with a
 triangular grid) = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and FETCH_SIZE reports half of
 the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section); the two counters come from separate
-passes (TCC slot limit).  Usage: python scripts/pmc_traffic.py <fetch_dir> <write_dir> [U]"""
+passes (TCC slot limit).  Usage: python scripts/pmc_traffic.py <fetch_dir> <write_dir> [order of the factorised system]"""
 import csv, glob, json, os, sys
 
 def dispatches(d, counter):
     f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
     out = []
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] == counter and "gemm_f64_kernel<0, 0>" in r["Kernel_Name"]:
+        if r["Counter_Name"] == counter and "gemm_f64_kernel<0, 0, 128, 128>" in r["Kernel_Name"]:
             out.append((int(r["Grid_Size"]) // 256, float(r["Counter_Value"])))
     return out
 
 def main():
     fetch_dir, write_dir = sys.argv[1], sys.argv[2]
-    U = int(sys.argv[3]) if len(sys.argv) > 3 else 18014
+    U = int(sys.argv[3]) if len(sys.argv) > 3 else 15014   # order of the factorised (EO-reduced) system at config 4
     nb, bo = (U + 127) // 128, 4
-    # tile counts of the trailing updates (b) of csrc/dense.hip::potrf: T = nb - K2, tiles = T(T+1)/2, T >= 17 only
-    # (smaller triangular counts collide with the tile counts of the panel GEMMs)
+    nbr = nb + 1                                             # block rows: the right-hand-side rows ride along
+    # tile counts of the trailing updates (b) of csrc/dense.hip::potrf: T = nbr - K2, tiles = T(T+1)/2, T >= 17 only
+    # (smaller triangular counts collide with the tile counts of other launches)
     tiles = set()
-    K0 = 0
-    while K0 + bo < nb:
-        K2 = min(K0 + 2 * bo, nb)
-        T = nb - K2
-        if T >= 17:
+    K1 = bo
+    while K1 < nb:
+        K2 = min(K1 + bo, nb)
+        T = nbr - K2
+        if T >= 17 and K2 < nb:
             tiles.add(T * (T + 1) // 2)
-        K0 += bo
+        K1 = K2
     fe = [v for g, v in dispatches(fetch_dir, "FETCH_SIZE") if g in tiles]
     wr = [v for g, v in dispatches(write_dir, "WRITE_SIZE") if g in tiles]
     n = min(len(fe), len(wr))
