@@ -533,25 +533,31 @@ hipError_t DenseSolver::potrf() {
     }
     int K0 = 0, K1 = width(0) < nb ? width(0) : nb;
     HIPCHK(panel(sp, 0, K1));
-    hipEvent_t e_panel = next_event(), e_upd = nullptr;
+    hipEvent_t e_panel = next_event();
     if (la) HIPCHK(hipEventRecord(e_panel, sp));
     while (K1 < nb) {
         const int K2 = (K1 + width(K1) < nb) ? K1 + width(K1) : nb;     // end of the next panel
+        if (la) HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
         const int Kw = (K1 - K0) * 128;
-        // (a) columns of the next panel: rows >= K1, cols [K1,K2).  It runs on the panel stream, ahead of the panel it
-        // feeds, and concurrently with (b) below: both only read panel [K0,K1) and write disjoint columns, so the chip
-        // stays full while the critical columns get the free slots first (stream priority).  It must follow the
-        // previous (b), which wrote the same columns.
-        if (la && e_upd) HIPCHK(hipStreamWaitEvent(sp, e_upd, 0));
+        // (a) columns of the next panel: rows >= K1, cols [K1,K2)
         GemmArgs a{};
         a.A = L + (long)(K1 * 128) * ld + K0 * 128; a.lda = ld; a.B = a.A; a.ldb = ld;
         a.C = L + (long)(K1 * 128) * ld + K1 * 128; a.ldc = ld;
         a.M = n - K1 * 128; a.N = (K2 - K1) * 128; a.K = Kw; a.alpha = -1.0; a.beta = 1.0; a.lower_only = 0; a.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(sp, LAY_KC, LAY_KC, a));
-        // (b) the rest of the trailing matrix: rows, cols >= K2 (lower tiles), on the update stream
+        HIPCHK(gemm_f64(su, LAY_KC, LAY_KC, a));
+        if (la) {
+            hipEvent_t e = next_event();
+            HIPCHK(hipEventRecord(e, su));
+            HIPCHK(hipStreamWaitEvent(sp, e, 0));
+        }
+        HIPCHK(panel(sp, K1, K2));
+        if (la) {
+            e_panel = next_event();
+            HIPCHK(hipEventRecord(e_panel, sp));
+        }
+        // (b) the rest of the trailing matrix: rows, cols >= K2 (lower tiles)
         const int rows = n - K2 * 128;
         if (rows > 0 && K2 < nb) {
-            if (la) HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
             GemmArgs u{};
             u.A = L + (long)(K2 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
             u.C = L + (long)(K2 * 128) * ld + K2 * 128; u.ldc = ld;
@@ -571,15 +577,6 @@ hipError_t DenseSolver::potrf() {
                 u.n_map = it->second.second;
             }
             HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
-            if (la) {
-                e_upd = next_event();
-                HIPCHK(hipEventRecord(e_upd, su));
-            }
-        }
-        HIPCHK(panel(sp, K1, K2));
-        if (la) {
-            e_panel = next_event();
-            HIPCHK(hipEventRecord(e_panel, sp));
         }
         K0 = K1;
         K1 = K2;
