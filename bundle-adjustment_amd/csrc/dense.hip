@@ -386,8 +386,9 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, greatest));
-        // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask enables CU i/8 of every XCD):
-        // the trailing updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.
+        // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask is CU i/8 of XCD i%8): the trailing
+        // updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.  (Reserving fewer CUs was
+        // measured: one or two reserved CUs cost 5 ms per factorisation at config 4, eight cost the update 3 % of the chip.)
         if (nfact >= 2048 && !getenv("JAICOV_NO_CUMASK")) {
             uint32_t upd[8], dia[8];
             for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
@@ -457,13 +458,17 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
         double *Akk = L + (long)(k * 128) * ld + k * 128;
         const int rows_k = n - k * 128;
         const bool split = dstream != nullptr && st == pstream && rows_k > tail_rows;
+        // While the trailing update still hides the panel (many rows left) the panel GEMMs take the 128-tile: it costs
+        // the update fewer CU slots per flop than the 64-tile latency variant, which is for the critical-path regime.
+        static const int bulk_rows = getenv("JAICOV_BULK_ROWS") ? atoi(getenv("JAICOV_BULK_ROWS")) : 9216;
+        const int small = (st == pstream && rows_k > bulk_rows) ? 0 : -1;
         if (k > K0) {
             GemmArgs c{};
             c.A = L + (long)(k * 128) * ld + K0 * 128; c.lda = ld;      // L[k*128:n, K0*128 : k*128]
             c.B = c.A; c.ldb = ld;                                       // first 128 rows of the same strip
             c.C = Akk; c.ldc = ld; c.M = rows_k; c.N = 128; c.K = (k - K0) * 128;
             c.alpha = -1.0; c.beta = 1.0; c.lower_only = 0; c.kmode = KMODE_FULL;
-            HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, c));
+            HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, c, 1, small));
         }
         hipStream_t ds = st;
         if (split) {
@@ -485,7 +490,7 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
         // L21 = A21 * inv(L11)'   (in place: one column tile, every workgroup reads and writes only its own rows)
         g.A = A21; g.lda = ld; g.B = invd + (long)k * 16384; g.ldb = 128; g.C = A21; g.ldc = ld;
         g.M = rows; g.N = 128; g.K = 128; g.alpha = 1.0; g.beta = 0.0; g.lower_only = 0; g.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, g));
+        HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, g, 1, small));
     }
     return hipGetLastError();
 }
@@ -521,7 +526,8 @@ hipError_t DenseSolver::potrf() {
         return rows > big_rows ? 2 * bo : (rows > small_rows ? bo : (bo > 1 ? bo / 2 : 1));
     };
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
-    const bool la = lookahead && pstream != nullptr && nb > bo;
+    static const bool no_la = getenv("JAICOV_NO_LOOKAHEAD") != nullptr;
+    const bool la = lookahead && !no_la && pstream != nullptr && nb > bo;
     ev_used = 0;
     hipStream_t sp = la ? pstream : stream;                 // panel GEMMs
     hipStream_t su = la && ustream ? ustream : stream;      // trailing updates (all CUs but the reserved ones)
