@@ -27,7 +27,9 @@ def main():
         K2 = min(K1 + bo, nb)
         T = nbr - K2
         if T >= 17 and K2 < nb:
-            tiles.add(T * (T + 1) // 2)
+            t = T * (T + 1) // 2
+            tiles.add(t)
+            tiles.add(8 * ((t + 7) // 8))    # launches with the XCD-aware tile map: 8 lists of ceil(t/8) workgroups
         K1 = K2
     fe = [v for g, v in dispatches(fetch_dir, "FETCH_SIZE") if g in tiles]
     wr = [v for g, v in dispatches(write_dir, "WRITE_SIZE") if g in tiles]
