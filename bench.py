@@ -188,6 +188,23 @@ def main():
             out["final_pass_ms"] = 1e3 * (time.perf_counter() - t1)
             out["final_pass_stage_ms"] = eng.timings()
             out["sigma0_ratio"] = om / fp.degree_of_freedom / s2 if world == 1 else None
+        # final pass of MatrixInversion.REDUCED / PRE_ELIMINATION (BA:261-267): cofactor matrix of the border, points,
+        # interior orientation and distortion only = inverse of the EO-reduced system (the second run is reported,
+        # the first one allocates the inverse's buffers)
+        for rep in range(2):
+            sync()
+            t2 = time.perf_counter()
+            if use_dist:
+                distributed.sharded_step(eng, dist, torch.device("cuda", local), s2, invert=engine.INVERT_REDUCED)
+            else:
+                eng.prepare_inverse(engine.INVERT_REDUCED)
+                eng.build(s2, 0.0)
+                eng.solve(engine.INVERT_REDUCED)
+            sync()
+            if rank == 0:
+                out["final_pass_reduced_ms"] = 1e3 * (time.perf_counter() - t2)
+                out["final_pass_reduced_stage_ms"] = eng.timings()
+                out["final_pass_reduced_order"] = eng.cofactor_order()
     if rank == 0:
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fp, eng, s2)

@@ -88,21 +88,21 @@ __global__ void scale_vec_kernel(const double *n, const double *V, double *out, 
 }
 
 // final cofactor: Qxx[i][j] = V_i V_j (Q[i][j] - sum_a G[a][i] H[a][j]) on the unknown block, border from F, E.
-// G, H, F: [d][Upad]; E: [d][d].  Lower part (j <= i) only.
+// G: [d][gs]; H, F: [d][Upad]; E: [d][d].  Lower part (j <= i) of the leading `order` rows only.
 __global__ __launch_bounds__(256) void qfix_kernel(double *__restrict__ Q, long ld, int U, int Upad, int d,
-                                                   const double *__restrict__ V, const double *__restrict__ G,
+                                                   const double *__restrict__ V, const double *__restrict__ G, long gs,
                                                    const double *__restrict__ H, const double *__restrict__ F,
-                                                   const double *__restrict__ E) {
+                                                   const double *__restrict__ E, int order) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int i = blockIdx.y;
-    if (j > i || j >= Upad) return;
+    if (j > i || j >= order) return;
     double v;
     if (i >= U) v = 0.0;
     else if (i < d) v = E[i * d + j];
     else if (j < d) v = F[(long)j * Upad + i];
     else {
         v = Q[(long)i * ld + j];
-        for (int a = 0; a < d; a++) v -= G[(long)a * Upad + i] * H[(long)a * Upad + j];
+        for (int a = 0; a < d; a++) v -= G[(long)a * gs + i] * H[(long)a * Upad + j];
         v *= V[i] * V[j];
     }
     Q[(long)i * ld + j] = v;
@@ -171,7 +171,10 @@ struct jaicov_engine {
     uint8_t *d_in_block = nullptr;
     PPGather pp;
     // EO pre-elimination (schur.hip)
-    bool schur_ok = false, schur_active = false, want_inverse_next = false;
+    bool schur_ok = false, schur_active = false;
+    int inverse_mode_next = 0;       // JAICOV_INVERT_* announced for the solve after the next build
+    int q_order = 0;                 // order of the cofactor matrix on the device (U, or e0 for the reduced one)
+    bool q_reduced = false, solverS_has_inverse = false;
     std::vector<int> h_blk_images;   // image of every block handled by this engine
     std::vector<int32_t> ip_old2new; // empty, or: engine position of the caller's observation (dense blocks are column-sorted)
     int e0 = 0;                   // first EO column == order of the reduced system
@@ -685,7 +688,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     int rc = ensure_rows(e);
     if (rc) return rc;
     HIPE(e, hipEventRecord(e->ev[1], e->stream));
-    e->schur_active = e->schur_ok && !e->want_inverse_next;
+    e->schur_active = e->schur_ok && e->inverse_mode_next != JAICOV_INVERT_FULL;
     {   // only the lower triangle of N is ever written or read (nadd, pack, scale_copy); the reduced system has e0 rows
         const int rows = e->schur_active ? std::min(e->Upad, ((e->e0 + 127) / 128) * 128) : e->Upad;
         hipLaunchKernelGGL(zero_lower_kernel, dim3((rows + 1023) / 1024, rows), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, rows);
@@ -778,8 +781,14 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
 
 extern "C" int jaicov_neq_prepare_inverse(jaicov_engine *e, int inverse_follows) {
     if (!e) return JAICOV_ERR_BAD_ARGUMENT;
-    e->want_inverse_next = inverse_follows != 0;
+    if (inverse_follows < 0 || inverse_follows > JAICOV_INVERT_REDUCED) return JAICOV_ERR_BAD_ARGUMENT;
+    e->inverse_mode_next = inverse_follows;
     return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_cofactor_order(const jaicov_engine *e) {
+    if (!e || !e->have_Q) return -1;
+    return e->q_order;
 }
 
 extern "C" int jaicov_neq_reduced_order(const jaicov_engine *e) {
@@ -853,9 +862,10 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     if (e->state != jaicov_engine::ST_BUILT) FAIL(e, JAICOV_ERR_BAD_STATE, "build first");
     HIPE(e, hipSetDevice(e->device));
     const bool schur = e->schur_active;
-    if (schur && invert)
+    if (invert < 0 || invert > JAICOV_INVERT_REDUCED) return JAICOV_ERR_BAD_ARGUMENT;
+    if (schur && invert == JAICOV_INVERT_FULL)
         FAIL(e, JAICOV_ERR_BAD_STATE, "the normal equations were assembled with the EO blocks pre-eliminated: call "
-                                      "jaicov_neq_prepare_inverse(e, 1) before the build whose solve shall invert");
+                                      "jaicov_neq_prepare_inverse(e, JAICOV_INVERT_FULL) before the build whose solve shall invert");
     // order of the system that is factorised: the reduced one (points, IO, distortion) or the full one
     const int U = schur ? e->e0 : e->U, d = e->d, nrhs = d + 1;
     const int Upad = e->Upad;                      // leading dimension of N, V, B and the rhs/solution vectors
@@ -873,14 +883,15 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         HIPE(e, hipStreamSynchronize(e->stream));
         if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
     }
-    if (invert && !e->solver_has_inverse) {
-        const size_t sq = (size_t)e->solver.n * e->solver.ld * sizeof(double);
-        HIPE(e, hipMalloc(&e->solver.W, sq));
-        HIPE(e, hipMalloc(&e->solver.Q, sq));
-        const size_t half = (size_t)(Upad / 2 + 128);
-        e->solver.T_elems = half * half;
-        HIPE(e, hipMalloc(&e->solver.T, e->solver.T_elems * sizeof(double)));
-        e->solver_has_inverse = true;
+    bool &has_inv = schur ? e->solverS_has_inverse : e->solver_has_inverse;
+    if (invert && !has_inv) {
+        const size_t sq = (size_t)slv.n * slv.ld * sizeof(double);
+        HIPE(e, hipMalloc(&slv.W, sq));
+        HIPE(e, hipMalloc(&slv.Q, sq));
+        const size_t half = (size_t)(slv.nfact / 2 + 128);
+        slv.T_elems = half * half;
+        HIPE(e, hipMalloc(&slv.T, slv.T_elems * sizeof(double)));
+        has_inv = true;
     }
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
     HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -966,8 +977,11 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
             }
     }
     if (invert) {
-        HIPE(e, e->solver.trtri());
-        HIPE(e, e->solver.lauum());
+        // FULL: Qxx of all unknowns.  REDUCED on a pre-eliminated system: the inverse of the reduced normal equations,
+        // which IS the block of Qxx that belongs to the datum border, points, interior orientation and distortion
+        // (MatrixInversion.REDUCED / PRE_ELIMINATION, BA:261-267: solve(N, n, numRows, true) on the reduced system).
+        HIPE(e, slv.trtri());
+        HIPE(e, slv.lauum());
         // H = Sinv G^ ; F = R (Sinv G^) V ; E = R (I - Sinv) R
         std::vector<double> H((size_t)8 * Upad, 0.0), F((size_t)8 * Upad, 0.0);
         double E[49];
@@ -985,11 +999,13 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
             HIPE(e, hipMemcpyAsync(e->d_F, F.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
             HIPE(e, hipMemcpyAsync(e->d_E, E, (size_t)d * d * sizeof(double), hipMemcpyHostToDevice, e->stream));
         }
-        hipLaunchKernelGGL(qfix_kernel, dim3((Upad + 255) / 256, Upad), dim3(256), 0, e->stream, e->solver.Q, ld, U, Upad, d,
-                           e->d_V, e->d_G + Upad, e->d_H, e->d_F, e->d_E);
+        hipLaunchKernelGGL(qfix_kernel, dim3((Up + 255) / 256, Up), dim3(256), 0, e->stream, slv.Q, ld, U, Upad, d,
+                           e->d_V, e->d_G + vs, (long)vs, e->d_H, e->d_F, e->d_E, Up);
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
         e->have_Q = true;
+        e->q_reduced = schur;
+        e->q_order = U;
     } else {
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
@@ -1077,12 +1093,13 @@ extern "C" int jaicov_neq_get_normal(jaicov_engine *e, double *N_packed, size_t 
 extern "C" int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_t len) {
     if (!e || !Q_packed) return JAICOV_ERR_BAD_ARGUMENT;
     if (!e->have_Q) FAIL(e, JAICOV_ERR_BAD_STATE, "no cofactor matrix: solve with invert != 0 first (MatrixInversion.NONE, BA:1177)");
-    const int U = e->U;
-    if (len != (size_t)U * (U + 1) / 2) return JAICOV_ERR_BAD_ARGUMENT;
+    const int U = e->q_order;
+    if (len != (size_t)U * (U + 1) / 2) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "cofactor buffer length must be order(order+1)/2 with order = jaicov_neq_cofactor_order()");
     HIPE(e, hipSetDevice(e->device));
+    const DenseSolver &qs = e->q_reduced ? e->solverS : e->solver;
     double *d_ap = nullptr;
     HIPE(e, hipMalloc(&d_ap, std::max<size_t>(len, 1) * sizeof(double)));
-    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, e->solver.Q, e->solver.ld, U, d_ap);
+    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, qs.Q, qs.ld, U, d_ap);
     hipError_t he = hipMemcpyAsync(Q_packed, d_ap, len * sizeof(double), hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     hipFree(d_ap);
@@ -1094,7 +1111,8 @@ extern "C" int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx,
     if (!e || !idx || !out || k <= 0) return JAICOV_ERR_BAD_ARGUMENT;
     if (!e->have_Q) FAIL(e, JAICOV_ERR_BAD_STATE, "no cofactor matrix: solve with invert != 0 first");
     for (int i = 0; i < k; i++)
-        if (idx[i] < 0 || idx[i] >= e->U) return JAICOV_ERR_BAD_ARGUMENT;
+        if (idx[i] < 0 || idx[i] >= e->q_order) return JAICOV_ERR_BAD_ARGUMENT;
+    const DenseSolver &qs = e->q_reduced ? e->solverS : e->solver;
     HIPE(e, hipSetDevice(e->device));
     int32_t *d_idx = nullptr;
     double *d_out = nullptr;
@@ -1102,7 +1120,7 @@ extern "C" int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx,
     hipError_t he = hipMalloc(&d_out, (size_t)k * k * sizeof(double));
     if (he == hipSuccess) he = hipMemcpyAsync(d_idx, idx, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) {
-        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, e->solver.Q, e->solver.ld, d_idx, k, d_out);
+        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, qs.Q, qs.ld, d_idx, k, d_out);
         he = hipMemcpyAsync(out, d_out, (size_t)k * k * sizeof(double), hipMemcpyDeviceToHost, e->stream);
     }
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -1150,7 +1168,8 @@ extern "C" int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n) 
     return JAICOV_OK;
 }
 
-// BA.estimateModel (BA:203-387) + updateModel (BA:389-442), FULL / NONE inversion modes
+// BA.estimateModel (BA:203-387) + updateModel (BA:389-442); inversion modes NONE / FULL / REDUCED (PRE_ELIMINATION = REDUCED:
+// the engine pre-eliminates the exterior orientations in every pass whenever the problem allows it)
 extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_options *o, jaicov_estimate_result *res) {
     if (!e || !o || !res || o->struct_size != sizeof(jaicov_estimate_options)) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
@@ -1172,12 +1191,12 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
         maxAbsDx = 0.0;
         iter = max_iter - runs;
         if (deriveFirst) { adapted = damping; deriveFirst = false; }
-        jaicov_neq_prepare_inverse(e, isEstimated && o->invert);
+        jaicov_neq_prepare_inverse(e, isEstimated ? o->invert : JAICOV_INVERT_NONE);
         rc = jaicov_neq_build(e, sigma2, adapted, o->simulation);
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
         if (rc) { state = rc == JAICOV_ERR_BAD_ARGUMENT || rc > 0 ? -2 : -1; break; }
         complete = isEstimated;
-        rc = jaicov_neq_solve(e, complete && o->invert, dx.data());
+        rc = jaicov_neq_solve(e, complete ? o->invert : JAICOV_INVERT_NONE, dx.data());
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
         if (rc) { state = (rc > 0 || rc == JAICOV_ERR_BAD_ARGUMENT) ? -2 : -1; break; }
         bool rejected = false;

@@ -22,7 +22,7 @@ STATUS = {0: "OK", -1: "BAD_ARGUMENT", -2: "BAD_STATE", -3: "UNSUPPORTED", -4: "
 EXPORTS = [
     "jaicov_neq_create", "jaicov_neq_destroy", "jaicov_neq_last_error", "jaicov_neq_abi_version",
     "jaicov_neq_num_slots", "jaicov_neq_packed_length", "jaicov_neq_set_parameters", "jaicov_neq_get_parameters",
-    "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_accumulate2", "jaicov_neq_prepare_inverse", "jaicov_neq_reduced_order",
+    "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_accumulate2", "jaicov_neq_prepare_inverse", "jaicov_neq_reduced_order", "jaicov_neq_cofactor_order",
     "jaicov_neq_finalize", "jaicov_neq_reduce_buffer",
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
@@ -31,6 +31,7 @@ EXPORTS = [
 ]
 
 KROW = 32  # 12 + JAICOV_MAX_DIST_PER_CAMERA
+INVERT_NONE, INVERT_FULL, INVERT_REDUCED = 0, 1, 2   # MatrixInversion (BundleAdjustment.java:65-70)
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)
@@ -94,6 +95,7 @@ def load_library():
     L.jaicov_neq_accumulate2.argtypes = [vp, C.c_double, C.c_double]
     L.jaicov_neq_prepare_inverse.argtypes = [vp, C.c_int]
     L.jaicov_neq_reduced_order.argtypes = [vp]
+    L.jaicov_neq_cofactor_order.argtypes = [vp]
     L.jaicov_neq_finalize.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.jaicov_neq_reduce_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.jaicov_neq_solve.argtypes = [vp, C.c_int, _pd]
@@ -177,8 +179,12 @@ class Engine:
         return int(self.L.jaicov_neq_reduced_order(self._h))
 
     def prepare_inverse(self, inverse_follows=True):
-        """Tell the engine that the solve after the next build inverts (final pass): it then assembles the full system."""
+        """Announce the `invert` value of the solve after the next build (final pass): INVERT_FULL (True) makes that
+        build assemble the full system, INVERT_REDUCED keeps the EO pre-elimination."""
         self._chk(self.L.jaicov_neq_prepare_inverse(self._h, int(inverse_follows)))
+
+    def cofactor_order(self):
+        return int(self.L.jaicov_neq_cofactor_order(self._h))
 
     def finalize(self, sigma2, lam=0.0, simulation=False):
         self._chk(self.L.jaicov_neq_finalize(self._h, sigma2, lam, int(simulation)))
@@ -212,7 +218,11 @@ class Engine:
         return N, n
 
     def get_cofactor(self):
-        Q = np.zeros(self.fp.packed_length)
+        """Packed 'U' cofactor matrix of order cofactor_order() (U after INVERT_FULL, reduced_order() after INVERT_REDUCED)."""
+        k = self.cofactor_order()
+        if k < 0:
+            raise EngineError(-2, "no cofactor matrix: solve with invert != 0 first")
+        Q = np.zeros(k * (k + 1) // 2)
         self._chk(self.L.jaicov_neq_get_cofactor(self._h, _p(Q), Q.size))
         return Q
 

@@ -348,9 +348,14 @@ EstimationStateType BundleAdjustment::estimateModel() {
     if ((rc = jaicov_neq_set_parameters(engine_, f.values.data(), f.values.size())) != JAICOV_OK) return fail(rc);
     const int U = d.n_unknowns;
     const bool simulation = estimationType_ == EstimationType::SIMULATION;
-    // REDUCED / PRE_ELIMINATION differ from FULL only in how the same system is solved (Schur elimination of the EO
-    // blocks, BundleAdjustment.java:1197-1453); they are served by the full solve here.
+    // REDUCED / PRE_ELIMINATION (BA:261-267, 283-291, 1197-1453): the final pass inverts the system from which the
+    // exterior orientations were eliminated, so Qxx holds the block of the datum border, the points, the interior
+    // orientation and the distortion parameters only.  The engine eliminates the EO blocks itself in every pass whenever
+    // the problem allows it (jaicov_neq_reduced_order() < U), whatever the mode; where it cannot, REDUCED is served by the
+    // full inverse (a superset of what the reference leaves in N).
     const bool wantInverse = inversion_ != MatrixInversion::NONE;
+    const int invertMode = inversion_ == MatrixInversion::NONE ? JAICOV_INVERT_NONE
+                         : inversion_ == MatrixInversion::FULL ? JAICOV_INVERT_FULL : JAICOV_INVERT_REDUCED;
     std::vector<double> dx((size_t)std::max(U, 1));
     EstimationStateType status = EstimationStateType::BUSY;
     do {
@@ -358,12 +363,12 @@ EstimationStateType BundleAdjustment::estimateModel() {
         iterationStep_ = maxIter_ - runs;
         fire("ITERATE", maxIter_, iterationStep_);
         if (deriveFirst) { adapted = damping_; deriveFirst = false; }                         // BA:801-812
-        jaicov_neq_prepare_inverse(engine_, isEstimated && wantInverse ? 1 : 0);   // BA:250: the final pass is known before it is built
+        jaicov_neq_prepare_inverse(engine_, isEstimated ? invertMode : JAICOV_INVERT_NONE);   // BA:250: the final pass is known before it is built
         if ((rc = jaicov_neq_build(engine_, sigma2apriori_, adapted, simulation ? 1 : 0)) != JAICOV_OK) return fail(rc);   // BA:235
         if (interrupt_) { interrupt_ = false; return EstimationStateType::INTERRUPT; }         // BA:240-245
         complete = isEstimated;
         if (complete && wantInverse) fire("INVERT_NORMAL_EQUATION_MATRIX", 0, 1);
-        if ((rc = jaicov_neq_solve(engine_, complete && wantInverse ? 1 : 0, dx.data())) != JAICOV_OK) return fail(rc);     // BA:270,294
+        if ((rc = jaicov_neq_solve(engine_, complete ? invertMode : JAICOV_INVERT_NONE, dx.data())) != JAICOV_OK) return fail(rc);     // BA:264,270,294
         // ---- updateModel (BA:389-442) ----
         bool rejected = false;
         if (adapted > 0) {
@@ -410,8 +415,11 @@ EstimationStateType BundleAdjustment::estimateModel() {
     if ((rc = jaicov_neq_get_parameters(engine_, v.data(), v.size())) != JAICOV_OK) return fail(rc);
     pullValues(v);
     if (wantInverse) {
-        Qxx_.resize(jaicov_neq_packed_length(engine_));
-        if ((rc = jaicov_neq_get_cofactor(engine_, Qxx_.data(), Qxx_.size())) != JAICOV_OK) return fail(rc);   // BA:274
+        // packed 'U' (column-major upper): the leading k x k block is the leading k(k+1)/2 entries, so the reduced
+        // cofactor matrix lands where the reference's in-place solve(N, n, numRows, true) leaves it (BA:264,274)
+        const size_t k = (size_t)jaicov_neq_cofactor_order(engine_);
+        Qxx_.assign(jaicov_neq_packed_length(engine_), 0.0);
+        if ((rc = jaicov_neq_get_cofactor(engine_, Qxx_.data(), k * (k + 1) / 2)) != JAICOV_OK) return fail(rc);
     }
     if (centroided_) centroidCoordinates(true);      // BA:357-358
     status = isConverge ? EstimationStateType::ERROR_FREE_ESTIMATION : EstimationStateType::NO_CONVERGENCE;   // BA:377-384

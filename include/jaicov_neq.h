@@ -172,10 +172,22 @@ int jaicov_neq_accumulate(jaicov_engine *e, double sigma2apriori);
 /* accumulate with the LM damping value known up front (needed when the engine pre-eliminates the exterior-orientation
  * blocks per image while assembling, the device-side form of MatrixInversion.PRE_ELIMINATION, BA:283-291,1197-1453). */
 int jaicov_neq_accumulate2(jaicov_engine *e, double sigma2apriori, double lambda);
-/* Announces that the solve after the NEXT build will be called with invert != 0 (the final pass, BA:252-280): that
- * build then assembles the full system instead of the EO-reduced one.  estimateModel knows this before it builds
- * (BA:250 estimateCompleteModel = isEstimated).                                                                     */
+/* MatrixInversion (BA:65-70) as the `invert` argument of prepare_inverse / solve / estimate:
+ * NONE: no cofactor matrix.  FULL: Qxx = K^-1 of all u + d unknowns (BA:268-271).  REDUCED: the block of Qxx that belongs
+ * to the datum border, the object points, the interior orientation and the distortion parameters, i.e. the inverse of
+ * the system from which the exterior orientations were eliminated -- what MatrixInversion.REDUCED and PRE_ELIMINATION
+ * keep in the final pass (BA:261-267: reduceNormalEquationSystem + solve(N, n, numRows, true)); when the engine cannot
+ * pre-eliminate (jaicov_neq_reduced_order() == U) REDUCED is served by the full inverse.                           */
+#define JAICOV_INVERT_NONE    0
+#define JAICOV_INVERT_FULL    1
+#define JAICOV_INVERT_REDUCED 2
+/* Announces the `invert` value of the solve after the NEXT build (the final pass, BA:252-280): FULL makes that build
+ * assemble the full system instead of the EO-reduced one.  estimateModel knows this before it builds (BA:250
+ * estimateCompleteModel = isEstimated).                                                                            */
 int jaicov_neq_prepare_inverse(jaicov_engine *e, int inverse_follows);
+/* Order of the cofactor matrix the last inverting solve left on the device: U (FULL) or jaicov_neq_reduced_order()
+ * (REDUCED on a pre-eliminated system); -1 without one.                                                            */
+int jaicov_neq_cofactor_order(const jaicov_engine *e);
 /* Order of the system the last accumulate assembled: U, or the first EO column when the EO blocks were pre-eliminated
  * (then every rank's solve returns dx with only ITS images' EO entries filled; a multi-GPU host sums dx[order..U)).   */
 int jaicov_neq_reduced_order(const jaicov_engine *e);
@@ -189,7 +201,7 @@ int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count)
 
 /* replaces NES.applyPrecondition (NES:82-91) + MX.solve(N,n,numRows,invert) (MX:338-366) + the reverse
  * preconditioning (BA:273,297).  dx_out[U] (border entries = Lagrange multipliers, as dspsv leaves them).
- * invert != 0 keeps Qxx = K^-1 on the device (BA:274).                                                   */
+ * invert = JAICOV_INVERT_*: != NONE keeps Qxx on the device (BA:274).                                     */
 int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out);
 
 /* replaces BA.getOmega(dx) (BA:472-491): sum over groups of (w - A dx)' P (w - A dx) at the CURRENT
@@ -203,7 +215,7 @@ int jaicov_neq_update(jaicov_engine *e, const double *dx, double *max_abs_dx);
 /* --- results ----------------------------------------------------------------------------------------- */
 /* N (after finalize, before preconditioning) and n in packed 'U' order, for UpperSymmPackMatrix.getData() */
 int jaicov_neq_get_normal(jaicov_engine *e, double *N_packed, size_t len, double *n, size_t U);
-/* Qxx = K^-1 (BA:1177 getCofactorMatrix), packed 'U', order U.  Requires a solve with invert != 0.        */
+/* Qxx (BA:1177 getCofactorMatrix), packed 'U', order jaicov_neq_cofactor_order().  Requires an inverting solve. */
 int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_t len);
 /* sub-matrix gather Q[idx[i], idx[j]] into a dense row-major k x k buffer (what MatlabResultWriter.java:210-221
  * and DefaultResultWriter.java:126-155 read element-wise).                                               */
@@ -216,7 +228,7 @@ int jaicov_neq_get_rows(jaicov_engine *e, int32_t ip_begin, int32_t ip_count, do
 typedef struct jaicov_estimate_options {
     uint32_t struct_size;
     int32_t  max_iterations;       /* DefaultValue.java:25 = 5000                                        */
-    int32_t  invert;               /* 0 = MatrixInversion.NONE, 1 = FULL (BA:65-70)                      */
+    int32_t  invert;               /* JAICOV_INVERT_* = MatrixInversion (BA:65-70)                       */
     int32_t  simulation;           /* EstimationType.SIMULATION (BA:830)                                 */
     double   lambda0;              /* setLevenbergMarquardtDampingValue (BA:1189)                        */
     double   sigma2apriori;        /* BA:98,641                                                          */

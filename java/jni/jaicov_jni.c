@@ -73,11 +73,18 @@ JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_
     return jaicov_neq_build(ENG(h), s2, lambda, sim ? 1 : 0);
 }
 JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_NativeNormalEquationEngine_solve(
-    JNIEnv *e, jclass k, jlong h, jboolean invert, jdoubleArray dx) {
+    JNIEnv *e, jclass k, jlong h, jint invert, jdoubleArray dx) {   /* invert = JAICOV_INVERT_* = MatrixInversion (BA:65-70) */
     double *p = (*e)->GetPrimitiveArrayCritical(e, dx, NULL);
-    int rc = jaicov_neq_solve(ENG(h), invert ? 1 : 0, p);
+    int rc = jaicov_neq_solve(ENG(h), (int)invert, p);
     (*e)->ReleasePrimitiveArrayCritical(e, dx, p, 0);
     return rc;
+}
+JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_NativeNormalEquationEngine_prepareInverse(
+    JNIEnv *e, jclass k, jlong h, jint invert) {
+    return jaicov_neq_prepare_inverse(ENG(h), (int)invert);
+}
+JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_NativeNormalEquationEngine_cofactorOrder(JNIEnv *e, jclass k, jlong h) {
+    return jaicov_neq_cofactor_order(ENG(h));
 }
 JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_NativeNormalEquationEngine_omega(
     JNIEnv *e, jclass k, jlong h, jdouble s2, jdoubleArray dx, jdoubleArray out) {

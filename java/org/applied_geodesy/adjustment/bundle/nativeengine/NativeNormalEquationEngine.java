@@ -28,7 +28,15 @@ public final class NativeNormalEquationEngine implements AutoCloseable {
 	/** BA:235 createNormalEquation() */
 	public void build(double sigma2apriori, double lambda, boolean simulation) { check(build(handle, sigma2apriori, lambda, simulation)); }
 	/** NES.applyPrecondition + MathExtension.solve(N, n, invert) + reverse preconditioning (BA:238,270-297) */
-	public void solve(boolean invert, double[] dx) { check(solve(handle, invert, dx)); }
+	public void solve(int invert, double[] dx) { check(solve(handle, invert, dx)); }
+	/** MatrixInversion -> JAICOV_INVERT_*: NONE 0, FULL 1, REDUCED and PRE_ELIMINATION 2 (BA:65-70, 261-271) */
+	public static int invertMode(Enum<?> matrixInversion) {
+		switch (matrixInversion.name()) { case "NONE": return 0; case "FULL": return 1; default: return 2; }
+	}
+	/** announces the invert mode of the solve after the next build (BA:250: the final pass is known before it is built) */
+	public void prepareInverse(int invert) { check(prepareInverse(handle, invert)); }
+	/** order of the cofactor matrix of the last inverting solve: u + d (FULL) or numRows of BA:262 (REDUCED) */
+	public int cofactorOrder() { return cofactorOrder(handle); }
 	/** BA:472 getOmega(dx) */
 	public double omega(double sigma2apriori, double[] dx) { double[] o = new double[1]; check(omega(handle, sigma2apriori, dx, o)); return o[0]; }
 	/** BA:450 updateUnknownParameters(dx); returns max|dx| */
@@ -54,7 +62,9 @@ public final class NativeNormalEquationEngine implements AutoCloseable {
 	private static native int setParameters(long h, double[] slots);
 	private static native int getParameters(long h, double[] slots);
 	private static native int build(long h, double sigma2, double lambda, boolean simulation);
-	private static native int solve(long h, boolean invert, double[] dx);
+	private static native int solve(long h, int invert, double[] dx);
+	private static native int prepareInverse(long h, int invert);
+	private static native int cofactorOrder(long h);
 	private static native int omega(long h, double sigma2, double[] dx, double[] out);
 	private static native int update(long h, double[] dx, double[] maxAbs);
 	private static native int getCofactor(long h, double[] packed);

@@ -260,3 +260,40 @@ def test_eo_pre_elimination_sharded(oracle_mod):
     assert np.all(dx[e0:] != 0)
     for e_ in (full, a, b):
         e_.close()
+
+
+@pytest.mark.parametrize("free_network", [False, True])
+def test_reduced_inverse_is_the_block_of_the_full_cofactor(oracle_mod, free_network):
+    """MatrixInversion.REDUCED / PRE_ELIMINATION (BA:261-267): the final pass inverts the system from which the exterior
+    orientations were eliminated; that inverse is the (border, points, IO, distortion) block of the full Qxx = K^-1,
+    which the oracle computes with the reference's dspsv + dsptri on the full bordered system."""
+    if free_network:
+        fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=0, scale_bar=True)
+    else:
+        fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, True)
+    U, d = fp.n_unknowns, fp.rank_defect
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_REDUCED)
+    eng.build(s2, 0.0)
+    e0 = eng.reduced_order()
+    assert e0 == U - 6 * fp.n_images
+    dx = eng.solve(engine.INVERT_REDUCED)
+    np.testing.assert_allclose(dx[d:], dxo[d:], rtol=0, atol=1e-9 * np.abs(dxo[d:]).max())
+    assert eng.cofactor_order() == e0
+    Q = packed_to_full(eng.get_cofactor(), e0)
+    Qref = packed_to_full(Qo, U)[:e0, :e0]
+    sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
+    assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
+    assert np.abs(Q - Qref).max() <= 1e-8 * np.abs(Qref).max()
+    idx = np.array([d, d + 3, e0 - 1, d + 1], np.int32)
+    np.testing.assert_array_equal(eng.get_cofactor_sub(idx), Q[np.ix_(idx, idx)])
+    # FULL afterwards still works and agrees on the block
+    eng.prepare_inverse(engine.INVERT_FULL); eng.build(s2, 0.0); eng.solve(engine.INVERT_FULL)
+    assert eng.cofactor_order() == U
+    Qf = packed_to_full(eng.get_cofactor(), U)
+    assert (np.abs(Qf[:e0, :e0] - Q)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
+    eng.close()

@@ -199,3 +199,25 @@ def test_example_centroided_equals_uncentroided(H, example_base):
         assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
         res.append(np.array([[p.getX().getValue(), p.getY().getValue(), p.getZ().getValue()] for p in ba.getObjectCoordinates()]))
     assert np.abs(res[0] - res[1]).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["REDUCED", "PRE_ELIMINATION"])
+def test_example_reduced_inversion_modes(H, example_base, mode):
+    """MatrixInversion.REDUCED / PRE_ELIMINATION (BundleAdjustment.java:261-267,283-291): same adjusted parameters as FULL
+    and the same cofactor block for the datum border, points, interior orientation and distortion (the leading
+    numRows of Qxx).  The bundled block has no jointly dispersed image groups, so the engine serves the mode with the
+    full inverse here; the pre-eliminated route is covered by test_gpu_parity.py::test_reduced_inverse_*."""
+    res = {}
+    for m in ("FULL", mode):
+        pr, ba = example_adjustment(H, example_base)
+        ba.setInvertNormalEquation(getattr(H.MatrixInversion, m))
+        assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+        pts = np.array([[p.getX().getValue(), p.getY().getValue(), p.getZ().getValue()] for p in ba.getObjectCoordinates()])
+        res[m] = (pts, np.array(ba.getCofactorMatrix()), ba.getIterations())
+    assert res["FULL"][2] == res[mode][2]
+    np.testing.assert_allclose(res[mode][0], res["FULL"][0], rtol=0, atol=1e-9)
+    k = 6 + 3 * len(res["FULL"][0]) + 7          # d + 3P + (c, x0, y0, A1, A2, Bx, By): numRows of BA:262
+    n = k * (k + 1) // 2
+    ref = res["FULL"][1][:n]
+    np.testing.assert_allclose(res[mode][1][:n], ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())   # two runs: atomics reorder sums
