@@ -36,9 +36,7 @@ struct DenseSolver {
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse
-    double *Q = nullptr;       // n x ld : (L L')^-1 (lower tiles valid; symmetrize() fills the rest)
-    double *T = nullptr;       // workspace of the recursive triangular inverse
-    size_t T_elems = 0;
+    double *Q = nullptr;       // n x ld : (L L')^-1 (lower tiles valid; symmetrize() fills the rest); workspace of trtri()
     int *d_info = nullptr;     // first failing pivot (1-based), 0 = ok
     bool owns = false;
     // optional per-launch profiling of the trailing update (HIP events on `stream`)

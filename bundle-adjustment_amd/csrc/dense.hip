@@ -406,16 +406,13 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     if (with_inverse) {
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
-        const size_t half = (size_t)(nfact / 2 + 128);
-        T_elems = half * half;
-        HIPCHK(hipMalloc(&T, T_elems * sizeof(double)));
     }
     return hipSuccess;
 }
 
 void DenseSolver::release() {
     if (!owns) return;
-    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(T);
+    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q);
     for (auto &kv : tile_maps) hipFree(kv.second.first);
     tile_maps.clear();
     for (auto ev : prof_ev) hipEventDestroy(ev);
@@ -426,7 +423,7 @@ void DenseSolver::release() {
     if (ustream) hipStreamDestroy(ustream);
     if (dstream) hipStreamDestroy(dstream);
     pstream = ustream = dstream = nullptr;
-    L = invd = W = Q = T = nullptr;
+    L = invd = W = Q = nullptr;
     d_info = nullptr;
     owns = false;
 }
@@ -607,31 +604,40 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     return hipGetLastError();
 }
 
-// W[lo:hi, lo:hi] = inverse of L[lo:hi, lo:hi], recursively: off-diagonal block = -W22 * (L21 * W11)
-static hipError_t trtri_rec(DenseSolver &s, int lo, int hi) {
-    if (hi - lo <= 1) return hipSuccess;
-    const int mid = lo + (hi - lo) / 2;
-    HIPCHK(trtri_rec(s, lo, mid));
-    HIPCHK(trtri_rec(s, mid, hi));
-    const int M = (hi - mid) * 128, N = (mid - lo) * 128;
-    GemmArgs t{};
-    t.A = s.L + (long)(mid * 128) * s.ld + lo * 128; t.lda = s.ld;          // L21 (KC)
-    t.B = s.W + (long)(lo * 128) * s.ld + lo * 128; t.ldb = s.ld;           // W11 (k,j) row-major = XC, lower-triangular
-    t.C = s.T; t.ldc = N; t.M = M; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 0.0; t.kmode = KMODE_GE_COL;
-    HIPCHK(gemm_f64(s.stream, LAY_KC, LAY_XC, t));
-    GemmArgs w{};
-    w.A = s.W + (long)(mid * 128) * s.ld + mid * 128; w.lda = s.ld;         // W22 (KC), lower-triangular
-    w.B = s.T; w.ldb = N;                                                   // T (k,j) row-major = XC
-    w.C = s.W + (long)(mid * 128) * s.ld + lo * 128; w.ldc = s.ld;
-    w.M = M; w.N = N; w.K = M; w.alpha = -1.0; w.beta = 0.0; w.kmode = KMODE_LE_ROW;
-    return gemm_f64(s.stream, LAY_KC, LAY_XC, w);
-}
-
+// W = L^-1 (lower), level by level from the inverted diagonal blocks upwards.  At level h (blocks of h x 128 columns)
+// every pair [lo, lo+h) | [lo+h, lo+2h) is merged independently:  W21 = -W22 (L21 W11).  All full pairs of a level
+// have the same shape and a constant address stride, so a level is two batched launches (product T = L21 W11 into the
+// W21-position of Q, which is free until lauum() fills it; then W21 = -W22 T); a ragged last pair gets its own two.
 hipError_t DenseSolver::trtri() {
     const int nb = nfact / 128;
+    if (!Q) return hipErrorInvalidValue;
     HIPCHK(hipMemsetAsync(W, 0, (size_t)n * ld * sizeof(double), stream));
     hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(nb), dim3(256), 0, stream, invd, W, ld);
-    return trtri_rec(*this, 0, nb);
+    for (int h = 1; h < nb; h *= 2) {
+        const int full = nb / (2 * h);                         // pairs with both halves complete
+        const long pair_stride = (long)(2 * h) * 128 * (ld + 1);
+        auto merge = [&](int lo, int mid, int hi, int batch) -> hipError_t {
+            const int M = (hi - mid) * 128, N = (mid - lo) * 128;
+            GemmArgs t{};
+            t.A = L + (long)(mid * 128) * ld + lo * 128; t.lda = ld;          // L21 (KC)
+            t.B = W + (long)(lo * 128) * ld + lo * 128; t.ldb = ld;           // W11 (k,j) row-major = XC, lower-triangular
+            t.C = Q + (long)(mid * 128) * ld + lo * 128; t.ldc = ld;
+            t.M = M; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 0.0; t.kmode = KMODE_GE_COL;
+            t.strideA = t.strideB = t.strideC = pair_stride;
+            HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, t, batch));
+            GemmArgs w{};
+            w.A = W + (long)(mid * 128) * ld + mid * 128; w.lda = ld;         // W22 (KC), lower-triangular
+            w.B = t.C; w.ldb = ld;                                            // T (k,j) row-major = XC
+            w.C = W + (long)(mid * 128) * ld + lo * 128; w.ldc = ld;
+            w.M = M; w.N = N; w.K = M; w.alpha = -1.0; w.beta = 0.0; w.kmode = KMODE_LE_ROW;
+            w.strideA = w.strideB = w.strideC = pair_stride;
+            return gemm_f64(stream, LAY_KC, LAY_XC, w, batch);
+        };
+        if (full > 0) HIPCHK(merge(0, h, 2 * h, full));
+        const int lo = full * 2 * h, mid = lo + h;
+        if (mid < nb) HIPCHK(merge(lo, mid, nb, 1));          // ragged pair: second half shorter than h
+    }
+    return hipGetLastError();
 }
 
 hipError_t DenseSolver::lauum() {

@@ -888,9 +888,6 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         const size_t sq = (size_t)slv.n * slv.ld * sizeof(double);
         HIPE(e, hipMalloc(&slv.W, sq));
         HIPE(e, hipMalloc(&slv.Q, sq));
-        const size_t half = (size_t)(slv.nfact / 2 + 128);
-        slv.T_elems = half * half;
-        HIPE(e, hipMalloc(&slv.T, slv.T_elems * sizeof(double)));
         has_inv = true;
     }
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
