@@ -69,6 +69,18 @@ struct SchurBufs {
     double lambda = 0.0;
 };
 
+// assembly_mode = 1 (densemode.hip): workspace and driver of the densified MFMA contraction of the image groups
+struct DenseMode {
+    double *Ppad = nullptr, *Apad = nullptr, *Bbuf = nullptr, *Sbuf = nullptr;
+    int32_t *cmap = nullptr;
+    int mpad = 0, kpad = 0, batch = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t init(int max_m, int max_k1, int n_blocks);
+    void release();
+    hipError_t assemble(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, const double *rowsA,
+                        const double *rowsW, double sigma2, double *N, double *n, float *gemm_ms);
+};
+
 // ---- slot layout ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int slot_io(const DevProblem &p, int c) { return 3 * p.n_points + 3 * c; }
 __device__ __forceinline__ int slot_dist(const DevProblem &p, int j) { return 3 * p.n_points + 3 * p.n_cameras + j; }

@@ -172,6 +172,9 @@ struct jaicov_engine {
     PPGather pp;
     // EO pre-elimination (schur.hip)
     bool schur_ok = false, schur_active = false;
+    DenseMode dm;                    // assembly_mode = 1
+    bool dense_mode = false;
+    double dm_flops_per_pass = 0.0, dm_stat_passes = 0.0, dm_stat_ms = 0.0, dm_stat_flops = 0.0;
     int inverse_mode_next = 0;       // JAICOV_INVERT_* announced for the solve after the next build
     int q_order = 0;                 // order of the cofactor matrix on the device (U, or e0 for the reduced one)
     bool q_reduced = false, solverS_has_inverse = false;
@@ -271,6 +274,7 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     if (e->stream) hipStreamSynchronize(e->stream);
     e->solver.release();
     e->solverS.release();
+    e->dm.release();
     for (void *ptr : e->allocs) hipFree(ptr);
     for (auto &evt : e->ev)
         if (evt) hipEventDestroy(evt);
@@ -605,6 +609,19 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     {
         const char *env = getenv("JAICOV_SCHUR");
         bool ok = !(env && env[0] == '0') && D->n_images > 0 && D->n_image_blocks > 0 && e->n_seg == 0 && e->n_blk_ip == e->ip_count;
+        if (e->opts.assembly_mode == 1 && e->n_blk_list > 0) {   // densified MFMA contraction of the image groups (densemode.hip)
+            int max_k1 = 0;
+            for (int g : blk_list) {
+                const int mp = D->blk_ip_begin[g + 1] - D->blk_ip_begin[g], cam = D->image_camera[D->ip_image[D->blk_ip_begin[g]]];
+                const int k1 = 3 * mp + 9 + D->cam_dist_begin[cam + 1] - D->cam_dist_begin[cam] + 1;
+                max_k1 = std::max(max_k1, k1);
+                e->dm_flops_per_pass += 2.0 * (2.0 * mp) * (2.0 * mp) * k1 + (2.0 * mp) * k1 * (k1 + 1.0);
+            }
+            HIPE(e, e->dm.init(e->max_m, max_k1, e->n_blk_list));
+            e->dense_mode = true;
+            ok = false;
+        } else if (e->opts.assembly_mode != 0 && e->opts.assembly_mode != 1)
+            FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "assembly_mode must be 0 (structure-aware) or 1 (densified MFMA contraction)");
         const int e0 = D->n_images > 0 ? D->eo_col[0] : -1;
         ok = ok && e0 >= d && e0 + 6 * D->n_images == U;
         for (int i = 0; ok && i < 6 * D->n_images; i++) ok = D->eo_col[i] == e0 + i;
@@ -702,8 +719,14 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
         HIPE(e, hipMemsetAsync(e->sb.info, 0, sizeof(int), e->stream));
         HIPE(e, hipMemsetAsync(e->sb.diagcorr, 0, (size_t)e->Upad * sizeof(double), e->stream));
     }
-    HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
-                                   e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, e->pp, sb));
+    if (e->dense_mode) {
+        float ms = 0.f;
+        HIPE(e, e->dm.assemble(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n,
+                               e->solver.profile ? &ms : nullptr));
+        if (e->solver.profile) { e->dm_stat_passes += 1.0; e->dm_stat_ms += ms; e->dm_stat_flops += e->dm_flops_per_pass; }
+    } else
+        HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
+                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, e->pp, sb));
     if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, e->d_N, e->d_n, nullptr, nullptr));
     HIPE(e, hipEventRecord(e->ev[2], e->stream));
     e->state = jaicov_engine::ST_ACCUMULATED;
@@ -1155,7 +1178,8 @@ extern "C" int jaicov_neq_set_profiling(jaicov_engine *e, int enable) {
 extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset) {
     if (!e || !stats || n < 3) return JAICOV_ERR_BAD_ARGUMENT;
     stats[0] = e->solver.stat_launches; stats[1] = e->solver.stat_ms; stats[2] = e->solver.stat_flops;
-    if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = 0.0;
+    if (n >= 6) { stats[3] = e->dm_stat_passes; stats[4] = e->dm_stat_ms; stats[5] = e->dm_stat_flops; }
+    if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = e->dm_stat_passes = e->dm_stat_ms = e->dm_stat_flops = 0.0;
     return JAICOV_OK;
 }
 

@@ -123,7 +123,7 @@ def _p(a):
 class Engine:
     """One engine per adjustment (``BundleAdjustment`` is single-shot: BundleAdjustment.java:203)."""
 
-    def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True):
+    def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0):
         self.L = load_library()
         self.fp = fp
         self.U = fp.n_unknowns
@@ -133,6 +133,7 @@ class Engine:
         opts.device = device
         opts.image_begin, opts.image_end = image_range if image_range is not None else (-1, -1)
         opts.apply_shared = int(apply_shared)
+        opts.assembly_mode = int(assembly_mode)
         self._h = C.c_void_p()
         rc = self.L.jaicov_neq_create(C.byref(self._desc), C.byref(opts), C.byref(self._h))
         if rc != 0:
@@ -246,9 +247,9 @@ class Engine:
         self._chk(self.L.jaicov_neq_set_profiling(self._h, int(on)))
 
     def kernel_stats(self, reset=False):
-        st = np.zeros(3)
-        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 3, int(reset)))
-        return {"launches": st[0], "ms": st[1], "flops": st[2]}
+        st = np.zeros(6)
+        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 6, int(reset)))
+        return {"launches": st[0], "ms": st[1], "flops": st[2], "dense_passes": st[3], "dense_gemm_ms": st[4], "dense_flops": st[5]}
 
     def estimate(self, values=None, sigma2=None, lam0=0.0, max_iter=5000, invert=True, simulation=False):
         """``BundleAdjustment.estimateModel()`` (BundleAdjustment.java:203-387) run natively on the engine."""

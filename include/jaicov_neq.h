@@ -139,7 +139,9 @@ typedef struct jaicov_engine_options {
      * apply_shared != 0 ... after the reduction they are identical everywhere.  -1/-1 = all images.     */
     int32_t  image_begin, image_end;
     int32_t  apply_shared;
-    int32_t  assembly_mode;        /* 0 = structure-aware (default), 1 = densified MFMA contraction of image blocks */
+    int32_t  assembly_mode;        /* 0 = structure-aware (default); 1 = J'WJ of the jointly dispersed image groups as a
+                                      dense contraction A'(PA) on the fp64 matrix cores (PDF:486-498 literally; ~50x the
+                                      arithmetic, for the MFMA-utilisation figure and as a second path for parity tests) */
     int32_t  block_size;           /* factorisation block NB; 0 = default                                */
     int32_t  reserved[8];
 } jaicov_engine_options;
@@ -253,7 +255,9 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
 
 /* Per-kernel profiling of the dominant kernel (the fp64 MFMA trailing update of the factorisation): when enabled,
  * every such launch is bracketed by HIP events on the engine stream.  stats: [0] launches, [1] summed device ms,
- * [2] summed algorithmic flops (rows*(rows+1)*K per lower-triangular update), since the last reset.            */
+ * [2] summed algorithmic flops (rows*(rows+1)*K per lower-triangular update), since the last reset.  With n >= 6 and
+ * assembly_mode = 1: [3] passes, [4] summed device ms of the two J'WJ GEMM launches per batch of images, [5] summed
+ * algorithmic flops of SURVEY 8(d)'s dense-group row, sum_g 2 m^2 (k+1) + m (k+1)(k+2).                              */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset);
 

@@ -297,3 +297,39 @@ def test_reduced_inverse_is_the_block_of_the_full_cofactor(oracle_mod, free_netw
     Qf = packed_to_full(eng.get_cofactor(), U)
     assert (np.abs(Qf[:e0, :e0] - Q)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["tiny_block", "mid_block"])
+def test_dense_contraction_mode_matches_structure_aware_and_oracle(oracle_mod, name):
+    """assembly_mode = 1 (densemode.hip): J'WJ of the jointly dispersed image groups as the dense contraction A'(PA) on the
+    matrix cores -- the literal full-weight branch of stackNormalEquationSystem (PDF:486-498) -- must give the normal
+    equations of the structure-aware path and of the oracle, and the same step."""
+    fp = scene.config(name) if name == "tiny_block" else scene.make_scene(12, 150, 90, dist=scene.DIST_FULL, weights="block",
+                                                                         n_control=5, control_dense=True)
+    s2 = fp.sigma2apriori
+    U = fp.n_unknowns
+    dense = engine.Engine(fp, assembly_mode=1)
+    dense.set_parameters(fp.values)
+    dense.build(s2, 0.0)
+    assert dense.reduced_order() == U            # no EO pre-elimination in this mode
+    Nd, nd = dense.get_normal()
+    ref = engine.Engine(fp)
+    ref.set_parameters(fp.values)
+    ref.prepare_inverse(engine.INVERT_FULL)      # full system from the structure-aware kernels
+    ref.build(s2, 0.0)
+    Ns, ns = ref.get_normal()
+    Nf, Nsf = packed_to_full(Nd, U), packed_to_full(Ns, U)
+    dg = np.sqrt(np.abs(np.diag(Nsf))); dg[dg == 0] = 1.0
+    assert (np.abs(Nf - Nsf) / np.outer(dg, dg)).max() < 1e-11
+    np.testing.assert_allclose(nd, ns, rtol=0, atol=1e-10 * np.abs(ns).max())
+    if name == "tiny_block":
+        No, no, _ = oracle_mod.Oracle(fp).build(fp.values, s2, 0.0)
+        Nof = packed_to_full(No, U)
+        assert (np.abs(Nf - Nof) / np.outer(dg, dg)).max() < 1e-11
+    dxd, dxs = dense.solve(False), ref.solve(engine.INVERT_FULL)
+    np.testing.assert_allclose(dxd, dxs, rtol=0, atol=1e-9 * np.abs(dxs).max())
+    dense.set_profiling(True); dense.kernel_stats(reset=True)
+    dense.build(s2, 0.0)
+    ks = dense.kernel_stats()
+    assert ks["dense_passes"] == 1 and ks["dense_gemm_ms"] > 0 and ks["dense_flops"] > 0
+    dense.close(); ref.close()
