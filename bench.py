@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="cfg4")
+    ap.add_argument("--iterations-only", action="store_true",
+                    help="only the timed LM passes (no final passes, no dense-mode measurement, no CPU baseline): profiling runs")
     ap.add_argument("--no-dense-mode", action="store_true", help="skip the densified J'WJ MFMA measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -160,7 +162,7 @@ def main():
                                    f"{fp.n_image_blocks} dense per-image dispersion blocks, U={U}, d={fp.rank_defect}",
                        "parallelism": f"images sharded over {world} rank(s), packed N all-reduced, replicated solve"},
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items()},
-            "roofline": {"kernel": "gemm_f64_kernel<KC,KC> (Cholesky trailing update, fp64 MFMA 16x16x4)",
+            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update, fp64 MFMA 16x16x4; symbol as listed by rocprofv3)",
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": ks["launches"], "avg_launch_ms": ks["ms"] / max(ks["launches"], 1),
@@ -172,7 +174,7 @@ def main():
                 out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 pass
-    if True:
+    if not a.iterations_only:
         # final pass (BA:252-280): same build, then solve with the full inverse and omega -- reported, not `value`.
         # Run twice: the first call allocates the inverse's buffers (7.8 GB) and builds the tile maps of the full order.
         for rep in range(2):
@@ -193,7 +195,7 @@ def main():
         # final pass of MatrixInversion.REDUCED / PRE_ELIMINATION (BA:261-267): cofactor matrix of the border, points,
         # interior orientation and distortion only = inverse of the EO-reduced system (the second run is reported,
         # the first one allocates the inverse's buffers)
-        for rep in range(2):
+        for rep in range(0 if a.iterations_only else 2):
             sync()
             t2 = time.perf_counter()
             if use_dist:
@@ -207,7 +209,7 @@ def main():
                 out["final_pass_reduced_ms"] = 1e3 * (time.perf_counter() - t2)
                 out["final_pass_reduced_stage_ms"] = eng.timings()
                 out["final_pass_reduced_order"] = eng.cofactor_order()
-    if rank == 0 and world == 1 and not a.no_dense_mode:
+    if rank == 0 and world == 1 and not a.no_dense_mode and not a.iterations_only:
         # BASELINE.json's second figure, "J'WJ MFMA-util%": the jointly dispersed image groups contracted as dense
         # A'(PA) on the fp64 matrix cores (engine option assembly_mode = 1, csrc/densemode.hip).  The default
         # structure-aware assembly computes the same N with ~2 % of the arithmetic; this is the literal form.
@@ -230,7 +232,7 @@ def main():
             "algorithmic_flops_per_pass": ks2["dense_flops"],
             "structure_aware_assembly_ms_per_pass": out["stage_ms_per_step"].get("assembly")}
     if rank == 0:
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and not a.iterations_only:
             out["cpu_baseline"] = cpu_baseline(fp, eng, s2)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)

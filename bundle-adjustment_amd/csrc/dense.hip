@@ -501,7 +501,7 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
         }
         HIPCHK(hipEventRecord(prof_ev[prof_used], st));
     }
-    HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, u));
+    HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, u, 1, 0, 1));   // own kernel symbol: gemm_f64_kernel<0, 0, 128, 128, 1>
     if (profile) {
         HIPCHK(hipEventRecord(prof_ev[prof_used + 1], st));
         prof_flops.push_back(flops);

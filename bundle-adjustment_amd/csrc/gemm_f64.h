@@ -46,7 +46,8 @@ struct GemmArgs {
 
 // TM = 128: the throughput tile described above.  TM = 64: latency variant for launches that cannot fill the chip with
 // 128-tiles (panel GEMMs of the factorisation): 4x the workgroups, each wave 32x32 = 2x2 MFMA tiles, LDS stride 80.
-template <int ALAY, int BLAY, int TM = 128, int TN = 128>
+// TAG only gives a launch site its own kernel symbol, so that rocprofv3 lists it separately (TAG 1 = Cholesky trailing update).
+template <int ALAY, int BLAY, int TM = 128, int TN = 128, int TAG = 0>
 __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(GemmArgs g) {
     constexpr int GEMM_BM = TM, GEMM_BN = TN;
     constexpr int LDA_S = TM + 16, LDB_S = TN + 16;   // LDS row strides: == 16 mod 32 doubles -> conflict-free fragments
@@ -267,7 +268,7 @@ inline std::vector<int2> xcd_tile_map(int T) {
 // Launches that cannot give every CU two 128-tiles (the regime in which the 128-tile runs at its rate) take the
 // 64-tile latency variant; `small_tiles` < 0 = that rule, 0 = never, 1 = always (rectangular KMODE_FULL calls only).
 constexpr int GEMM_SMALL_TILE_LIMIT = 480;
-inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1, int small_tiles = -1) {
+inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1, int small_tiles = -1, int tag = 0) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const int tm = g.M / 128, tn = g.N / 128;
     const int tiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
@@ -284,7 +285,8 @@ inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g,
         }
         return hipGetLastError();
     }
-    if (alay == LAY_KC && blay == LAY_KC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC>), grid, block, 0, s, g);
+    if (alay == LAY_KC && blay == LAY_KC && tag == 1) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 128, 128, 1>), grid, block, 0, s, g);
+    else if (alay == LAY_KC && blay == LAY_KC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC>), grid, block, 0, s, g);
     else if (alay == LAY_KC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_XC>), grid, block, 0, s, g);
     else if (alay == LAY_XC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_XC, LAY_XC>), grid, block, 0, s, g);
     else hipLaunchKernelGGL((gemm_f64_kernel<LAY_XC, LAY_KC>), grid, block, 0, s, g);
