@@ -190,7 +190,7 @@ struct jaicov_engine {
     double *d_vals = nullptr, *d_rowsA = nullptr, *d_rowsW = nullptr, *d_T = nullptr, *d_vbuf = nullptr;
     double *d_N = nullptr, *d_n = nullptr;          // one allocation: N (Upad x Upad) followed by n (Upad)
     double *d_packed = nullptr;                     // reduce buffer: packed N (U(U+1)/2) + n (U)
-    double *d_V = nullptr, *d_B = nullptr, *d_Y = nullptr, *d_Yw = nullptr, *d_X = nullptr, *d_dx = nullptr;
+    double *d_V = nullptr, *d_B = nullptr, *d_dx = nullptr;
     double *d_omega = nullptr, *d_G = nullptr, *d_H = nullptr, *d_F = nullptr, *d_E = nullptr;
     int32_t *d_idx = nullptr;
     DenseSolver solver;
@@ -594,9 +594,6 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     e->d_n = e->d_N + sq;
     if ((rc = dalloc(e, (size_t)e->Upad, &e->d_V))) return rc;
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_B, true))) return rc;
-    if ((rc = dalloc(e, (size_t)DENSE_MAX_RHS * e->Upad, &e->d_Y, true))) return rc;
-    if ((rc = dalloc(e, (size_t)DENSE_MAX_RHS * e->Upad, &e->d_Yw, true))) return rc;
-    if ((rc = dalloc(e, (size_t)DENSE_MAX_RHS * e->Upad, &e->d_X, true))) return rc;
     if ((rc = dalloc(e, (size_t)e->Upad, &e->d_dx, true))) return rc;
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_G, true))) return rc;
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_H, true))) return rc;
@@ -1277,7 +1274,7 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
     const int np = ((n + 127) / 128) * 128;
     DenseSolver ds;
     int status = JAICOV_OK;
-    double *d_ap = nullptr, *d_Y = nullptr, *d_Yw = nullptr, *d_X = nullptr;
+    double *d_ap = nullptr, *d_Y = nullptr;
     const size_t len = (size_t)n * (n + 1) / 2;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
@@ -1285,8 +1282,6 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
         if (ds.init(s, np, invert != 0, true) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
         if (hipMalloc(&d_ap, len * sizeof(double)) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
         hipMalloc(&d_Y, (size_t)DENSE_MAX_RHS * np * sizeof(double));
-        hipMalloc(&d_Yw, (size_t)DENSE_MAX_RHS * np * sizeof(double));
-        hipMalloc(&d_X, (size_t)DENSE_MAX_RHS * np * sizeof(double));
         hipMemcpyAsync(d_ap, ap, len * sizeof(double), hipMemcpyHostToDevice, s);
         // identity padding, then unpack the lower triangle
         hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np, (const int32_t *)nullptr);
@@ -1312,7 +1307,7 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
         if (ms_out) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); *ms_out = ms; }
     } while (0);
     hipStreamSynchronize(s);
-    hipFree(d_ap); hipFree(d_Y); hipFree(d_Yw); hipFree(d_X);
+    hipFree(d_ap); hipFree(d_Y);
     ds.release();
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipStreamDestroy(s);

@@ -1248,11 +1248,6 @@ int oracle_block_fair(const jaicov_problem_desc *d, const double *vals, double s
             for (int j = i; j < k; j++) N[pidx(cols[i], cols[j])] += a * tr[j];
         }
     }
-    /* the lower-left products a_j * t_i (i < j) that the upper loop skipped */
-    for (int r = 0; r < m; r++) {
-        const double *ar = A + (size_t)r * k, *tr = T + (size_t)r * k;
-        (void)ar; (void)tr;
-    }
     free(A); free(T); free(w); free(Pw); free(cols); free(pos);
     return 0;
 }
