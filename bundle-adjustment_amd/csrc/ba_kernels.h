@@ -71,11 +71,12 @@ struct SchurBufs {
 
 // assembly_mode = 1 (densemode.hip): workspace and driver of the densified MFMA contraction of the image groups
 struct DenseMode {
-    double *Ppad = nullptr, *Apad = nullptr, *Bbuf = nullptr, *Sbuf = nullptr;
+    void *Ppad = nullptr, *Apad = nullptr, *Bbuf = nullptr, *Sbuf = nullptr;   // double, or float when fp32
     int32_t *cmap = nullptr;
     int mpad = 0, kpad = 0, batch = 0;
+    bool fp32 = false;                       // assembly_mode = 2: fp32 operands and fp32 MFMA accumulation
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipError_t init(int max_m, int max_k1, int n_blocks);
+    hipError_t init(int max_m, int max_k1, int n_blocks, bool single);
     void release();
     hipError_t assemble(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, const double *rowsA,
                         const double *rowsW, double sigma2, double *N, double *n, float *gemm_ms);

@@ -11,6 +11,7 @@
 // 3 + kc non-zeros per row; this mode exists to measure "J'WJ MFMA utilisation" (BASELINE.json) and as an independent
 // second path for the parity tests.  The EO pre-elimination is off in this mode (the full system is assembled).
 #include "ba_kernels.h"
+#include "gemm_f32.h"
 #include "gemm_f64.h"
 
 namespace jaicov {
@@ -20,9 +21,11 @@ __device__ __forceinline__ int dm_shared_col(const DevProblem &p, int img, int c
     return c < 3 ? p.io_col[3 * cam + c] : (c < 9 ? p.eo_col[6 * img + (c - 3)] : p.dist_col[jb + (c - 9)]);
 }
 
-// P_g (m x m) -> Ppad (mpad x mpad, zero padded).  grid (mpad/256, mpad, batch)
+// P_g (m x m) -> Ppad (mpad x mpad, zero padded).  grid (mpad/256, mpad, batch).  T = double, or float for the
+// fp32-accumulate variant of BASELINE config 5 (assembly_mode = 2): operands rounded to fp32, fp32 MFMA accumulation.
+template <typename T>
 __global__ __launch_bounds__(256) void dm_pack_weight_kernel(DevProblem p, const int32_t *__restrict__ blk_list, int first,
-                                                             int n_list, double *__restrict__ Ppad, int mpad) {
+                                                             int n_list, T *__restrict__ Ppad, int mpad) {
     const int b = blockIdx.z;
     if (first + b >= n_list) return;
     const int g = blk_list[first + b];
@@ -30,14 +33,15 @@ __global__ __launch_bounds__(256) void dm_pack_weight_kernel(DevProblem p, const
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
     if (j >= mpad) return;
     const double *P = p.blk_w + p.blk_w_offset[g];
-    Ppad[(long)b * mpad * mpad + (long)i * mpad + j] = (i < m && j < m) ? P[(long)i * m + j] : 0.0;
+    Ppad[(long)b * mpad * mpad + (long)i * mpad + j] = (T)((i < m && j < m) ? P[(long)i * m + j] : 0.0);
 }
 
 // [A_g | w_g] -> Apad (mpad x kpad, zero padded; Apad must be zeroed before), column map cmap[b][kpad] (-1 = no column,
 // entry k = -2 marks the misclosure column).  grid (ceil(m/256), batch), thread = row of the group
+template <typename T>
 __global__ __launch_bounds__(256) void dm_pack_rows_kernel(DevProblem p, const int32_t *__restrict__ blk_list, int first,
                                                            int n_list, const double *__restrict__ rowsA,
-                                                           const double *__restrict__ rowsW, double *__restrict__ Apad,
+                                                           const double *__restrict__ rowsW, T *__restrict__ Apad,
                                                            int32_t *__restrict__ cmap, int mpad, int kpad) {
     const int b = blockIdx.y;
     if (first + b >= n_list) return;
@@ -60,15 +64,16 @@ __global__ __launch_bounds__(256) void dm_pack_rows_kernel(DevProblem p, const i
     }
     if (row >= m) return;
     const int q = row >> 1, r = row & 1;
-    double *out = Apad + (long)b * mpad * kpad + (long)row * kpad;
+    T *out = Apad + (long)b * mpad * kpad + (long)row * kpad;
 #pragma unroll
-    for (int a = 0; a < 3; a++) out[3 * q + a] = rowsA[(long)(2 * a + r) * S + ipb + q];
-    for (int c = 0; c < kc; c++) out[3 * mp + c] = rowsA[(long)(2 * dm_shared_local(c) + r) * S + ipb + q];
-    out[k] = rowsW[(long)r * S + ipb + q];
+    for (int a = 0; a < 3; a++) out[3 * q + a] = (T)rowsA[(long)(2 * a + r) * S + ipb + q];
+    for (int c = 0; c < kc; c++) out[3 * mp + c] = (T)rowsA[(long)(2 * dm_shared_local(c) + r) * S + ipb + q];
+    out[k] = (T)rowsW[(long)r * S + ipb + q];
 }
 
 // scatter of the lower triangle of S (kpad x kpad) through the column map.  grid (kpad/256, kpad, batch)
-__global__ __launch_bounds__(256) void dm_scatter_kernel(const double *__restrict__ Sbuf, const int32_t *__restrict__ cmap,
+template <typename T>
+__global__ __launch_bounds__(256) void dm_scatter_kernel(const T *__restrict__ Sbuf, const int32_t *__restrict__ cmap,
                                                          int first, int n_list, int kpad, double sigma2,
                                                          double *__restrict__ N, long ld, double *__restrict__ n) {
     const int b = blockIdx.z;
@@ -78,20 +83,22 @@ __global__ __launch_bounds__(256) void dm_scatter_kernel(const double *__restric
     const int32_t *cm = cmap + (long)b * kpad;
     const int ci = cm[i], cj = cm[j];
     if (ci == -1 || cj < 0) return;
-    const double v = sigma2 * Sbuf[(long)b * kpad * kpad + (long)i * kpad + j];
+    const double v = sigma2 * (double)Sbuf[(long)b * kpad * kpad + (long)i * kpad + j];
     if (ci == -2) unsafeAtomicAdd(n + cj, v);
     else nadd(N, ld, ci, cj, v);
 }
 
-hipError_t DenseMode::init(int max_m, int max_k1, int n_blocks) {
+hipError_t DenseMode::init(int max_m, int max_k1, int n_blocks, bool single) {
+    fp32 = single;
     mpad = ((max_m + 127) / 128) * 128;
     kpad = ((max_k1 + 127) / 128) * 128;
     batch = n_blocks < 16 ? (n_blocks > 0 ? n_blocks : 1) : 16;
+    const size_t es = fp32 ? sizeof(float) : sizeof(double);
     hipError_t he;
-    if ((he = hipMalloc(&Ppad, (size_t)batch * mpad * mpad * sizeof(double))) != hipSuccess) return he;
-    if ((he = hipMalloc(&Apad, (size_t)batch * mpad * kpad * sizeof(double))) != hipSuccess) return he;
-    if ((he = hipMalloc(&Bbuf, (size_t)batch * mpad * kpad * sizeof(double))) != hipSuccess) return he;
-    if ((he = hipMalloc(&Sbuf, (size_t)batch * kpad * kpad * sizeof(double))) != hipSuccess) return he;
+    if ((he = hipMalloc(&Ppad, (size_t)batch * mpad * mpad * es)) != hipSuccess) return he;
+    if ((he = hipMalloc(&Apad, (size_t)batch * mpad * kpad * es)) != hipSuccess) return he;
+    if ((he = hipMalloc(&Bbuf, (size_t)batch * mpad * kpad * es)) != hipSuccess) return he;
+    if ((he = hipMalloc(&Sbuf, (size_t)batch * kpad * kpad * es)) != hipSuccess) return he;
     if ((he = hipMalloc(&cmap, (size_t)batch * kpad * sizeof(int32_t))) != hipSuccess) return he;
     if ((he = hipEventCreate(&ev0)) != hipSuccess) return he;
     return hipEventCreate(&ev1);
@@ -104,32 +111,56 @@ void DenseMode::release() {
     Ppad = Apad = Bbuf = Sbuf = nullptr; cmap = nullptr; ev0 = ev1 = nullptr;
 }
 
+template <typename T>
+static hipError_t dm_batch(DenseMode &d, hipStream_t s, const DevProblem &p, const int32_t *blk_list, int first, int nb,
+                           int n_list, const double *rowsA, const double *rowsW, double sigma2, double *N, double *n) {
+    const int mpad = d.mpad, kpad = d.kpad;
+    T *Ppad = (T *)d.Ppad, *Apad = (T *)d.Apad, *Bbuf = (T *)d.Bbuf, *Sbuf = (T *)d.Sbuf;
+    hipError_t he = hipMemsetAsync(Apad, 0, (size_t)nb * mpad * kpad * sizeof(T), s);
+    if (he != hipSuccess) return he;
+    hipLaunchKernelGGL(dm_pack_weight_kernel<T>, dim3((mpad + 255) / 256, mpad, nb), dim3(256), 0, s, p, blk_list, first, n_list,
+                       Ppad, mpad);
+    hipLaunchKernelGGL(dm_pack_rows_kernel<T>, dim3((mpad + 255) / 256, nb), dim3(256), 0, s, p, blk_list, first, n_list, rowsA,
+                       rowsW, Apad, d.cmap, mpad, kpad);
+    if ((he = hipEventRecord(d.ev0, s)) != hipSuccess) return he;
+    if (sizeof(T) == sizeof(double)) {
+        GemmArgs g1{};   // B = P A
+        g1.A = (const double *)Ppad; g1.lda = mpad; g1.B = (const double *)Apad; g1.ldb = kpad; g1.C = (double *)Bbuf; g1.ldc = kpad;
+        g1.M = mpad; g1.N = kpad; g1.K = mpad; g1.alpha = 1.0; g1.beta = 0.0; g1.kmode = KMODE_FULL;
+        g1.strideA = (long)mpad * mpad; g1.strideB = (long)mpad * kpad; g1.strideC = (long)mpad * kpad;
+        if ((he = gemm_f64(s, LAY_KC, LAY_XC, g1, nb)) != hipSuccess) return he;
+        GemmArgs g2{};   // S = A' B, lower tiles
+        g2.A = (const double *)Apad; g2.lda = kpad; g2.B = (const double *)Bbuf; g2.ldb = kpad; g2.C = (double *)Sbuf; g2.ldc = kpad;
+        g2.M = kpad; g2.N = kpad; g2.K = mpad; g2.alpha = 1.0; g2.beta = 0.0; g2.lower_only = 1; g2.kmode = KMODE_FULL;
+        g2.strideA = (long)mpad * kpad; g2.strideB = (long)mpad * kpad; g2.strideC = (long)kpad * kpad;
+        if ((he = gemm_f64(s, LAY_XC, LAY_XC, g2, nb)) != hipSuccess) return he;
+    } else {
+        GemmArgsF g1{};
+        g1.A = (const float *)Ppad; g1.lda = mpad; g1.B = (const float *)Apad; g1.ldb = kpad; g1.C = (float *)Bbuf; g1.ldc = kpad;
+        g1.M = mpad; g1.N = kpad; g1.K = mpad;
+        g1.strideA = (long)mpad * mpad; g1.strideB = (long)mpad * kpad; g1.strideC = (long)mpad * kpad;
+        if ((he = gemm_f32(s, LAY_KC, LAY_XC, g1, nb)) != hipSuccess) return he;
+        GemmArgsF g2{};
+        g2.A = (const float *)Apad; g2.lda = kpad; g2.B = (const float *)Bbuf; g2.ldb = kpad; g2.C = (float *)Sbuf; g2.ldc = kpad;
+        g2.M = kpad; g2.N = kpad; g2.K = mpad; g2.lower_only = 1;
+        g2.strideA = (long)mpad * kpad; g2.strideB = (long)mpad * kpad; g2.strideC = (long)kpad * kpad;
+        if ((he = gemm_f32(s, LAY_XC, LAY_XC, g2, nb)) != hipSuccess) return he;
+    }
+    if ((he = hipEventRecord(d.ev1, s)) != hipSuccess) return he;
+    hipLaunchKernelGGL(dm_scatter_kernel<T>, dim3((kpad + 255) / 256, kpad, nb), dim3(256), 0, s, (const T *)Sbuf, d.cmap, first,
+                       n_list, kpad, sigma2, N, p.ld, n);
+    return hipGetLastError();
+}
+
 // returns the summed duration of the GEMM launches through *gemm_ms (HIP events on `s`)
 hipError_t DenseMode::assemble(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, const double *rowsA,
                                const double *rowsW, double sigma2, double *N, double *n, float *gemm_ms) {
     float total = 0.f;
     for (int first = 0; first < n_list; first += batch) {
         const int nb = n_list - first < batch ? n_list - first : batch;
-        hipError_t he = hipMemsetAsync(Apad, 0, (size_t)nb * mpad * kpad * sizeof(double), s);
+        hipError_t he = fp32 ? dm_batch<float>(*this, s, p, blk_list, first, nb, n_list, rowsA, rowsW, sigma2, N, n)
+                             : dm_batch<double>(*this, s, p, blk_list, first, nb, n_list, rowsA, rowsW, sigma2, N, n);
         if (he != hipSuccess) return he;
-        hipLaunchKernelGGL(dm_pack_weight_kernel, dim3((mpad + 255) / 256, mpad, nb), dim3(256), 0, s, p, blk_list, first, n_list,
-                           Ppad, mpad);
-        hipLaunchKernelGGL(dm_pack_rows_kernel, dim3((mpad + 255) / 256, nb), dim3(256), 0, s, p, blk_list, first, n_list, rowsA,
-                           rowsW, Apad, cmap, mpad, kpad);
-        if ((he = hipEventRecord(ev0, s)) != hipSuccess) return he;
-        GemmArgs g1{};   // B = P A
-        g1.A = Ppad; g1.lda = mpad; g1.B = Apad; g1.ldb = kpad; g1.C = Bbuf; g1.ldc = kpad;
-        g1.M = mpad; g1.N = kpad; g1.K = mpad; g1.alpha = 1.0; g1.beta = 0.0; g1.kmode = KMODE_FULL;
-        g1.strideA = (long)mpad * mpad; g1.strideB = (long)mpad * kpad; g1.strideC = (long)mpad * kpad;
-        if ((he = gemm_f64(s, LAY_KC, LAY_XC, g1, nb)) != hipSuccess) return he;
-        GemmArgs g2{};   // S = A' B, lower tiles
-        g2.A = Apad; g2.lda = kpad; g2.B = Bbuf; g2.ldb = kpad; g2.C = Sbuf; g2.ldc = kpad;
-        g2.M = kpad; g2.N = kpad; g2.K = mpad; g2.alpha = 1.0; g2.beta = 0.0; g2.lower_only = 1; g2.kmode = KMODE_FULL;
-        g2.strideA = (long)mpad * kpad; g2.strideB = (long)mpad * kpad; g2.strideC = (long)kpad * kpad;
-        if ((he = gemm_f64(s, LAY_XC, LAY_XC, g2, nb)) != hipSuccess) return he;
-        if ((he = hipEventRecord(ev1, s)) != hipSuccess) return he;
-        hipLaunchKernelGGL(dm_scatter_kernel, dim3((kpad + 255) / 256, kpad, nb), dim3(256), 0, s, Sbuf, cmap, first, n_list, kpad,
-                           sigma2, N, p.ld, n);
         if (gemm_ms) {
             if ((he = hipEventSynchronize(ev1)) != hipSuccess) return he;
             float ms = 0.f;

@@ -606,7 +606,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     {
         const char *env = getenv("JAICOV_SCHUR");
         bool ok = !(env && env[0] == '0') && D->n_images > 0 && D->n_image_blocks > 0 && e->n_seg == 0 && e->n_blk_ip == e->ip_count;
-        if (e->opts.assembly_mode == 1 && e->n_blk_list > 0) {   // densified MFMA contraction of the image groups (densemode.hip)
+        if ((e->opts.assembly_mode == 1 || e->opts.assembly_mode == 2) && e->n_blk_list > 0) {   // densified MFMA contraction of the image groups (densemode.hip)
             int max_k1 = 0;
             for (int g : blk_list) {
                 const int mp = D->blk_ip_begin[g + 1] - D->blk_ip_begin[g], cam = D->image_camera[D->ip_image[D->blk_ip_begin[g]]];
@@ -614,11 +614,11 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
                 max_k1 = std::max(max_k1, k1);
                 e->dm_flops_per_pass += 2.0 * (2.0 * mp) * (2.0 * mp) * k1 + (2.0 * mp) * k1 * (k1 + 1.0);
             }
-            HIPE(e, e->dm.init(e->max_m, max_k1, e->n_blk_list));
+            HIPE(e, e->dm.init(e->max_m, max_k1, e->n_blk_list, e->opts.assembly_mode == 2));
             e->dense_mode = true;
             ok = false;
-        } else if (e->opts.assembly_mode != 0 && e->opts.assembly_mode != 1)
-            FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "assembly_mode must be 0 (structure-aware) or 1 (densified MFMA contraction)");
+        } else if (e->opts.assembly_mode < 0 || e->opts.assembly_mode > 2)
+            FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "assembly_mode must be 0 (structure-aware), 1 (densified fp64 MFMA contraction) or 2 (the same with fp32 operands and accumulation)");
         const int e0 = D->n_images > 0 ? D->eo_col[0] : -1;
         ok = ok && e0 >= d && e0 + 6 * D->n_images == U;
         for (int i = 0; ok && i < 6 * D->n_images; i++) ok = D->eo_col[i] == e0 + i;

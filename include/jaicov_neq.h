@@ -141,7 +141,9 @@ typedef struct jaicov_engine_options {
     int32_t  apply_shared;
     int32_t  assembly_mode;        /* 0 = structure-aware (default); 1 = J'WJ of the jointly dispersed image groups as a
                                       dense contraction A'(PA) on the fp64 matrix cores (PDF:486-498 literally; ~50x the
-                                      arithmetic, for the MFMA-utilisation figure and as a second path for parity tests) */
+                                      arithmetic, for the MFMA-utilisation figure and as a second path for parity tests);
+                                      2 = mode 1 with operands rounded to fp32 and fp32 MFMA accumulation (BASELINE config 5's
+                                      precision sweep; NOT a product mode, results differ at the 1e-7 level by design)       */
     int32_t  block_size;           /* factorisation block NB; 0 = default                                */
     int32_t  reserved[8];
 } jaicov_engine_options;

@@ -126,8 +126,11 @@ def test_solve_matches_oracle(oracle_mod, name, invert):
         U = fp.n_unknowns
         Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
         sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
-        assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
-        np.testing.assert_allclose(np.diag(Q)[d:], np.diag(Qref)[d:], rtol=1e-9)
+        # tiny_block (5 images, 36 points) is poorly conditioned: the fp64 atomics of the assembly reorder sums from run to
+        # run and move Qxx by up to 1.2e-9 of sqrt(q_ii q_jj) (300 runs, scripts/flake_probe.py); the other scenes stay < 1e-10
+        tol = 1e-8 if name == "tiny_block" else 1e-9
+        assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < tol
+        np.testing.assert_allclose(np.diag(Q)[d:], np.diag(Qref)[d:], rtol=tol)
         assert np.abs(Q - Qref).max() <= 1e-8 * np.abs(Qref).max()
         idx = np.array([d, d + 3, U - 1, d + 1], np.int32)
         np.testing.assert_array_equal(eng.get_cofactor_sub(idx), Q[np.ix_(idx, idx)])
@@ -333,3 +336,23 @@ def test_dense_contraction_mode_matches_structure_aware_and_oracle(oracle_mod, n
     ks = dense.kernel_stats()
     assert ks["dense_passes"] == 1 and ks["dense_gemm_ms"] > 0 and ks["dense_flops"] > 0
     dense.close(); ref.close()
+
+
+def test_fp32_accumulate_contraction_is_measurably_worse(oracle_mod):
+    """BASELINE config 5's precision sweep in miniature (scripts/precision_sweep.py runs it at full size): assembly_mode = 2
+    contracts J'WJ with fp32 operands and fp32 MFMA accumulation.  On a 530-unknown scene the step moves by ~1e-3 of its
+    size and diag Qxx by ~1e-2 -- four to eight orders of magnitude above the fp64 paths; at config 3/4 size the fp32
+    normal matrix is no longer positive definite (profiles/r01_precision_sweep_*.json)."""
+    fp = scene.make_scene(12, 150, 90, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    s2 = fp.sigma2apriori
+    dxs = {}
+    for mode in (1, 2):
+        eng = engine.Engine(fp, assembly_mode=mode)
+        eng.set_parameters(fp.values)
+        eng.build(s2, 0.0)
+        dxs[mode] = eng.solve(False)
+        eng.close()
+    dev = np.abs(dxs[2] - dxs[1]).max() / np.abs(dxs[1]).max()
+    assert 1e-7 < dev < 1e-1
+    dxo, _, _, _ = oracle_mod.Oracle(fp).step(fp.values, s2, 0.0, False)
+    np.testing.assert_allclose(dxs[1], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
