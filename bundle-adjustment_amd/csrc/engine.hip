@@ -308,6 +308,15 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
         if (je - jb > JAICOV_MAX_DIST_PER_CAMERA) FAIL(e, JAICOV_ERR_UNSUPPORTED, "too many distortion coefficients for one camera");
         for (int j = jb + 1; j < je; j++)
             if (D->dist_kind[j] < D->dist_kind[j - 1]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "distortion coefficients must be in DistortionModel.Type order");
+        // AffinityShearDistortionModel always owns Cx and Cy, TangentialDistortionModel Bx and By (+ optional Bi): a lone
+        // member would silently drop out of the model (ASF:37-81, TDF:39-134 read both)
+        int cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int j = jb; j < je; j++) {
+            if (D->dist_kind[j] < 0 || D->dist_kind[j] > 6) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "unknown distortion coefficient kind");
+            cnt[D->dist_kind[j]]++;
+        }
+        if (cnt[0] != cnt[1] || cnt[0] > 1 || cnt[2] != cnt[3] || cnt[2] > 1 || (cnt[4] > 0 && cnt[2] == 0))
+            FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "affinity (Cx, Cy) and tangential (Bx, By [, Bi]) coefficients come as complete models");
     }
     for (int i = 1; i < D->n_image_points; i++)
         if (D->ip_image[i] < D->ip_image[i - 1]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "image points must be image-major");

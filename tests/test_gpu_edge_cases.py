@@ -122,3 +122,17 @@ def test_ragged_images(oracle_mod):
     rag = renumber(rag)
     reduced = check_against_oracle(oracle_mod, rag)
     assert reduced
+
+
+def test_incomplete_distortion_model_is_rejected():
+    """A lone Bx (TangentialDistortionModel always owns Bx and By, TDF:39-134) must not silently drop out of the model."""
+    base = scene.make_scene(6, 40, 24, dist=scene.DIST_FULL, weights="diag", n_control=4)
+    nd = base.dist_kind.size
+    keep = np.arange(nd) < 3                       # Cx, Cy, Bx
+    s = 3 * base.n_points + 3
+    bad = renumber(base, cam_dist_begin=np.array([0, 3], np.int32), dist_kind=base.dist_kind[keep].copy(),
+                   dist_order=base.dist_order[keep].copy(), truth=None,
+                   values=np.concatenate([base.values[:s], base.values[s:s + nd][keep], base.values[s + nd:]]))
+    with pytest.raises(engine.EngineError) as ei:
+        engine.Engine(bad)
+    assert ei.value.code == -1
