@@ -101,12 +101,6 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     use_dist = world > 1 or bool(os.environ.get("JAICOV_BENCH_FORCE_DIST"))   # the env var rehearses the collective path on 1 GPU
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29512")
-        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from bundle_adjustment_amd import distributed, engine, scene
 
     fp = scene.config(a.config)
@@ -114,6 +108,27 @@ def main():
     eng = engine.Engine(fp, device=local, image_range=(lo, hi) if use_dist else None, apply_shared=(rank == 0))
     eng.set_parameters(fp.values)
     s2 = fp.sigma2apriori
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints its version banner on stdout when the first communicator is created: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            # The communicator is created AFTER the engine and without device_id (lazy): created before the engine's
+            # streams it slowed the engine's multi-stream factorisation by 25 % on this stack (scripts/dist_ab.py:
+            # 30.1 -> 38.4 ms with world size 1), created afterwards it does not.
+            dist.init_process_group("nccl")
+            warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local))
+            dist.all_reduce(warm)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     def step():
         if use_dist:
@@ -127,7 +142,7 @@ def main():
     def sync():
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
             torch.cuda.synchronize()
 
     for _ in range(a.warmup):
@@ -238,7 +253,7 @@ def main():
         print(json.dumps(out), flush=True)
     eng.close()
     if use_dist:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

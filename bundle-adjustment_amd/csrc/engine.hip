@@ -644,6 +644,10 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = dalloc(e, (size_t)e->Upad, &e->sb.diagcorr, true))) return rc;
             e->schur_ok = true;
             e->e0 = e0;
+            // the solver of the reduced system is created here, with its streams, not at the first solve: stream creation
+            // order matters when the host also runs RCCL (bench.py: communicator after the engine)
+            HIPE(e, e->solverS.init(e->stream, ((e0 + 127) / 128) * 128, false, true));
+            e->solverS_ready = true;
         }
     }
     e->h_vals.assign(e->n_slots, 0.0);
@@ -839,7 +843,7 @@ extern "C" int jaicov_neq_build(jaicov_engine *e, double sigma2, double lambda, 
     return jaicov_neq_finalize(e, sigma2, lambda, simulation);
 }
 
-extern "C" int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count) {
+static int reduce_buffer_impl(jaicov_engine *e, void **device_ptr, size_t *count, bool sync) {
     if (!e || !device_ptr || !count) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state != jaicov_engine::ST_ACCUMULATED) FAIL(e, JAICOV_ERR_BAD_STATE, "accumulate first");
     HIPE(e, hipSetDevice(e->device));
@@ -853,11 +857,22 @@ extern "C" int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, siz
     }
     hipLaunchKernelGGL(pack_kernel, dim3((Ua + 255) / 256, std::max(Ua, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, Ua, e->d_packed);
     HIPE(e, hipMemcpyAsync(e->d_packed + len, e->d_n, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-    HIPE(e, hipStreamSynchronize(e->stream));   // the caller's collective runs on its own stream
+    if (sync) HIPE(e, hipStreamSynchronize(e->stream));   // the caller's collective runs on its own stream
     e->reduced = true;
     *device_ptr = e->d_packed;
     *count = len + Ua;
     return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count) {
+    return reduce_buffer_impl(e, device_ptr, count, true);
+}
+
+extern "C" int jaicov_neq_reduce_buffer_async(jaicov_engine *e, void **device_ptr, size_t *count, void **stream) {
+    if (!stream) return JAICOV_ERR_BAD_ARGUMENT;
+    const int rc = reduce_buffer_impl(e, device_ptr, count, false);
+    if (rc == JAICOV_OK) *stream = (void *)e->stream;
+    return rc;
 }
 
 // small dense helpers on the host (d <= 7)

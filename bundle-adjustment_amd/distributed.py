@@ -49,8 +49,20 @@ class DeviceArray:
 
 
 def allreduce_engine_buffer(eng, dist, device):
-    """Sums the engine's packed partial normal equations over all ranks, in place on the device."""
+    """Sums the engine's packed partial normal equations over all ranks, in place on the device.
+
+    On a GPU the collective is enqueued in the order of the engine's own stream (torch sees it as an ExternalStream: RCCL
+    waits for the pack kernel through stream events, the engine's finalize waits for RCCL the same way), so the host never
+    blocks and the factorisation's launches are queued while assembly and collective still run.  gloo (CPU rehearsal)
+    needs host tensors and takes the synchronous route."""
     import torch
+    if device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl":
+        ptr, cnt, stream = eng.reduce_buffer_async()
+        ext = torch.cuda.ExternalStream(stream, device=device)
+        with torch.cuda.stream(ext):
+            buf = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
+            dist.all_reduce(buf)
+        return
     ptr, cnt = eng.reduce_buffer()
     buf = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
     dist.all_reduce(buf)

@@ -23,7 +23,7 @@ EXPORTS = [
     "jaicov_neq_create", "jaicov_neq_destroy", "jaicov_neq_last_error", "jaicov_neq_abi_version",
     "jaicov_neq_num_slots", "jaicov_neq_packed_length", "jaicov_neq_set_parameters", "jaicov_neq_get_parameters",
     "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_accumulate2", "jaicov_neq_prepare_inverse", "jaicov_neq_reduced_order", "jaicov_neq_cofactor_order",
-    "jaicov_neq_finalize", "jaicov_neq_reduce_buffer",
+    "jaicov_neq_finalize", "jaicov_neq_reduce_buffer", "jaicov_neq_reduce_buffer_async",
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
     "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats",
@@ -98,6 +98,7 @@ def load_library():
     L.jaicov_neq_cofactor_order.argtypes = [vp]
     L.jaicov_neq_finalize.argtypes = [vp, C.c_double, C.c_double, C.c_int]
     L.jaicov_neq_reduce_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.jaicov_neq_reduce_buffer_async.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.jaicov_neq_solve.argtypes = [vp, C.c_int, _pd]
     L.jaicov_neq_omega.argtypes = [vp, C.c_double, _pd, _pd]
     L.jaicov_neq_update.argtypes = [vp, _pd, _pd]
@@ -194,6 +195,12 @@ class Engine:
         ptr = C.c_void_p(); cnt = C.c_size_t()
         self._chk(self.L.jaicov_neq_reduce_buffer(self._h, C.byref(ptr), C.byref(cnt)))
         return ptr.value, cnt.value
+
+    def reduce_buffer_async(self):
+        """(device pointer, count, hipStream_t) -- no host wait; the buffer is complete in the order of that stream."""
+        ptr = C.c_void_p(); cnt = C.c_size_t(); st = C.c_void_p()
+        self._chk(self.L.jaicov_neq_reduce_buffer_async(self._h, C.byref(ptr), C.byref(cnt), C.byref(st)))
+        return ptr.value, cnt.value, st.value
 
     def solve(self, invert=False):
         dx = np.zeros(max(self.U, 1))

@@ -202,6 +202,11 @@ int jaicov_neq_finalize(jaicov_engine *e, double sigma2apriori, double lambda, i
  * (ncclAllReduce, sum, double -- SURVEY 8(e)); finalize() picks the summed values up again.  The call synchronises
  * the engine stream so that the collective may run on any other stream.                                          */
 int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count);
+/* The same without the host-side wait: *stream receives the engine's hipStream_t; the buffer is complete in stream order.
+ * A host that enqueues its collective in that order (ncclAllReduce on this stream, or on a stream that waits for an event
+ * recorded here and is waited for before finalize) keeps the whole pass asynchronous, so the launch work of the
+ * factorisation overlaps the assembly and the collective instead of following them.                                */
+int jaicov_neq_reduce_buffer_async(jaicov_engine *e, void **device_ptr, size_t *count, void **stream);
 
 /* replaces NES.applyPrecondition (NES:82-91) + MX.solve(N,n,numRows,invert) (MX:338-366) + the reverse
  * preconditioning (BA:273,297).  dx_out[U] (border entries = Lagrange multipliers, as dspsv leaves them).

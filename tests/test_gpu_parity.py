@@ -209,7 +209,7 @@ def test_rccl_reduce_path_world1(oracle_mod):
     s2 = fp.sigma2apriori
     ref = engine.Engine(fp); ref.set_parameters(fp.values); ref.build(s2); dx_ref = ref.solve(False); ref.close()
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", rank=0, world_size=1)
     try:
         lo, hi = distributed.partition_images(fp, 1)[0]
         eng = engine.Engine(fp, image_range=(lo, hi), apply_shared=True)
