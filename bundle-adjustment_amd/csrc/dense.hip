@@ -403,6 +403,20 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
             }
         }
     }
+    // XCD-aware tile orders of every trailing-update size this solver can launch (one allocation, built here so that the
+    // first factorisation does not stop for host work)
+    if (xcd_maps && n / 128 >= 24) {
+        std::vector<int2> all;
+        std::vector<std::pair<int, std::pair<size_t, int>>> where;
+        for (int T = 24; T <= n / 128; T++) {
+            const std::vector<int2> m = xcd_tile_map(T);
+            where.push_back({T, {all.size(), (int)m.size()}});
+            all.insert(all.end(), m.begin(), m.end());
+        }
+        HIPCHK(hipMalloc(&tile_map_store, all.size() * sizeof(int2)));
+        HIPCHK(hipMemcpy(tile_map_store, all.data(), all.size() * sizeof(int2), hipMemcpyHostToDevice));
+        for (auto &w : where) tile_maps.emplace(w.first, std::make_pair(tile_map_store + w.second.first, w.second.second));
+    }
     if (with_inverse) {
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
@@ -413,7 +427,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
 void DenseSolver::release() {
     if (!owns) return;
     hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q);
-    for (auto &kv : tile_maps) hipFree(kv.second.first);
+    hipFree(tile_map_store);
+    tile_map_store = nullptr;
     tile_maps.clear();
     for (auto ev : prof_ev) hipEventDestroy(ev);
     prof_ev.clear();
@@ -569,15 +584,10 @@ hipError_t DenseSolver::potrf() {
             if (xcd_maps && !no_maps && rows / 128 >= 24) {
                 const int T = rows / 128;
                 auto it = tile_maps.find(T);
-                if (it == tile_maps.end()) {
-                    const std::vector<int2> m = xcd_tile_map(T);
-                    int2 *d = nullptr;
-                    HIPCHK(hipMalloc(&d, m.size() * sizeof(int2)));
-                    HIPCHK(hipMemcpy(d, m.data(), m.size() * sizeof(int2), hipMemcpyHostToDevice));
-                    it = tile_maps.emplace(T, std::make_pair(d, (int)m.size())).first;
+                if (it != tile_maps.end()) {
+                    u.tile_map = it->second.first;
+                    u.n_map = it->second.second;
                 }
-                u.tile_map = it->second.first;
-                u.n_map = it->second.second;
             }
             HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
         }
