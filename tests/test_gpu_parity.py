@@ -356,3 +356,26 @@ def test_fp32_accumulate_contraction_is_measurably_worse(oracle_mod):
     assert 1e-7 < dev < 1e-1
     dxo, _, _, _ = oracle_mod.Oracle(fp).step(fp.values, s2, 0.0, False)
     np.testing.assert_allclose(dxs[1], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+
+
+def test_config3_step_against_oracle(oracle_mod):
+    """BASELINE config 3 (100 images x 1 000 points, full interior set, 2x2 correlated image points, U = 3 614): one pass
+    against the oracle's packed Bunch-Kaufman solve, normal equations included."""
+    fp = scene.config("cfg3")
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    U = fp.n_unknowns
+    No, no, _ = o.build(fp.values, s2, 0.0)
+    dxo, _, _, _ = o.step(fp.values, s2, 0.0, False)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.build(s2, 0.0)
+    N, n = eng.get_normal()
+    dgo = np.sqrt(np.abs(No[np.arange(U) * (np.arange(U) + 3) // 2])); dgo[dgo == 0] = 1.0
+    r, c = np.triu_indices(U)                      # packed 'U' is column-major upper: index r + c(c+1)/2
+    rel = np.abs(N - No) / (dgo[r[np.argsort(r + c * (c + 1) // 2)]] * dgo[c[np.argsort(r + c * (c + 1) // 2)]])
+    assert rel.max() < 1e-11
+    np.testing.assert_allclose(n, no, rtol=0, atol=1e-11 * np.abs(no).max())
+    dx = eng.solve(False)
+    np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
+    eng.close()
