@@ -121,12 +121,12 @@ __global__ __launch_bounds__(256) void unpack_kernel(const double *__restrict__ 
     if (j > i || i >= U) return;
     M[(long)i * ld + j] = ap[(size_t)i * (i + 1) / 2 + j];
 }
-__global__ void gather_sub_kernel(const double *__restrict__ Q, long ld, const int32_t *idx, int k, double *out) {
+__global__ void gather_sub_kernel(const double *__restrict__ Q, long ld, const int32_t *idx, int k, double *out, double scale) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= k * k) return;
     const int a = t / k, b = t - a * k;
     const int i = idx[a], j = idx[b];
-    out[t] = i >= j ? Q[(long)i * ld + j] : Q[(long)j * ld + i];
+    out[t] = scale * (i >= j ? Q[(long)i * ld + j] : Q[(long)j * ld + i]);
 }
 // dense dispersion (row-major m x m) -> padded lower square with identity padding
 // perm (optional): engine point position -> caller's point position inside the block (rows 2q, 2q+1 move together)
@@ -1148,7 +1148,17 @@ extern "C" int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_
     return JAICOV_OK;
 }
 
+static int cofactor_sub_impl(jaicov_engine *e, const int32_t *idx, int32_t k, double scale, double *out);
+
 extern "C" int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx, int32_t k, double *out) {
+    return cofactor_sub_impl(e, idx, k, 1.0, out);
+}
+
+extern "C" int jaicov_neq_get_dispersion_sub(jaicov_engine *e, double sigma2_aposteriori, const int32_t *idx, int32_t k, double *out) {
+    return cofactor_sub_impl(e, idx, k, sigma2_aposteriori, out);
+}
+
+static int cofactor_sub_impl(jaicov_engine *e, const int32_t *idx, int32_t k, double scale, double *out) {
     if (!e || !idx || !out || k <= 0) return JAICOV_ERR_BAD_ARGUMENT;
     if (!e->have_Q) FAIL(e, JAICOV_ERR_BAD_STATE, "no cofactor matrix: solve with invert != 0 first");
     for (int i = 0; i < k; i++)
@@ -1161,7 +1171,7 @@ extern "C" int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx,
     hipError_t he = hipMalloc(&d_out, (size_t)k * k * sizeof(double));
     if (he == hipSuccess) he = hipMemcpyAsync(d_idx, idx, (size_t)k * sizeof(int32_t), hipMemcpyHostToDevice, e->stream);
     if (he == hipSuccess) {
-        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, qs.Q, qs.ld, d_idx, k, d_out);
+        hipLaunchKernelGGL(gather_sub_kernel, dim3(((size_t)k * k + 255) / 256), dim3(256), 0, e->stream, qs.Q, qs.ld, d_idx, k, d_out, scale);
         he = hipMemcpyAsync(out, d_out, (size_t)k * k * sizeof(double), hipMemcpyDeviceToHost, e->stream);
     }
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);

@@ -25,7 +25,7 @@ EXPORTS = [
     "jaicov_neq_build", "jaicov_neq_accumulate", "jaicov_neq_accumulate2", "jaicov_neq_prepare_inverse", "jaicov_neq_reduced_order", "jaicov_neq_cofactor_order",
     "jaicov_neq_finalize", "jaicov_neq_reduce_buffer", "jaicov_neq_reduce_buffer_async",
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
-    "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
+    "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_dispersion_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
     "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats",
     "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm",
 ]
@@ -105,6 +105,7 @@ def load_library():
     L.jaicov_neq_get_normal.argtypes = [vp, _pd, C.c_size_t, _pd, C.c_size_t]
     L.jaicov_neq_get_cofactor.argtypes = [vp, _pd, C.c_size_t]
     L.jaicov_neq_get_cofactor_sub.argtypes = [vp, _pi, C.c_int32, _pd]
+    L.jaicov_neq_get_dispersion_sub.argtypes = [vp, C.c_double, _pi, C.c_int32, _pd]
     L.jaicov_neq_get_rows.argtypes = [vp, C.c_int32, C.c_int32, _pd, _pd]
     L.jaicov_neq_estimate.argtypes = [vp, C.POINTER(EstimateOptions), C.POINTER(EstimateResult)]
     L.jaicov_neq_last_timings.argtypes = [vp, _pd, C.c_int32]
@@ -238,6 +239,13 @@ class Engine:
         idx = np.ascontiguousarray(idx, np.int32)
         out = np.zeros((idx.size, idx.size))
         self._chk(self.L.jaicov_neq_get_cofactor_sub(self._h, idx.ctypes.data_as(_pi), idx.size, _p(out)))
+        return out
+
+    def get_dispersion_sub(self, sigma2_aposteriori, idx):
+        """sigma2 * Qxx[idx, idx] gathered and scaled on the device (what the result writers print)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        out = np.zeros((idx.size, idx.size))
+        self._chk(self.L.jaicov_neq_get_dispersion_sub(self._h, float(sigma2_aposteriori), idx.ctypes.data_as(_pi), idx.size, _p(out)))
         return out
 
     def get_rows(self, ip_begin, ip_count):

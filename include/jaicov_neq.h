@@ -229,6 +229,9 @@ int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_t len);
 /* sub-matrix gather Q[idx[i], idx[j]] into a dense row-major k x k buffer (what MatlabResultWriter.java:210-221
  * and DefaultResultWriter.java:126-155 read element-wise).                                               */
 int jaicov_neq_get_cofactor_sub(jaicov_engine *e, const int32_t *idx, int32_t k, double *out);
+/* the same scaled on the device by the a-posteriori variance factor: sigma2 * Qxx[idx, idx], the dispersion block the
+ * writers print (DefaultResultWriter.java:126-155 `sigma2apost * cofactor.get(row, column)`) -- SURVEY 8(f) f2.      */
+int jaicov_neq_get_dispersion_sub(jaicov_engine *e, double sigma2_aposteriori, const int32_t *idx, int32_t k, double *out);
 /* compact residual/Jacobian rows of image point ip (debug / parity): w[2], A[2*(12+JAICOV_MAX_DIST_PER_CAMERA)]
  * in local order X,Y,Z,x0,y0,c,X0,Y0,Z0,omega,phi,kappa,dist...                                          */
 int jaicov_neq_get_rows(jaicov_engine *e, int32_t ip_begin, int32_t ip_count, double *w, double *A);

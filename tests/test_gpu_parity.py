@@ -134,6 +134,7 @@ def test_solve_matches_oracle(oracle_mod, name, invert):
         assert np.abs(Q - Qref).max() <= 1e-8 * np.abs(Qref).max()
         idx = np.array([d, d + 3, U - 1, d + 1], np.int32)
         np.testing.assert_array_equal(eng.get_cofactor_sub(idx), Q[np.ix_(idx, idx)])
+        np.testing.assert_array_equal(eng.get_dispersion_sub(0.37, idx), 0.37 * Q[np.ix_(idx, idx)])   # writers: sigma2apost * Qxx
     eng.close()
 
 
