@@ -222,7 +222,11 @@ int jaicov_neq_omega(jaicov_engine *e, double sigma2apriori, const double *dx, d
 int jaicov_neq_update(jaicov_engine *e, const double *dx, double *max_abs_dx);
 
 /* --- results ----------------------------------------------------------------------------------------- */
-/* N (after finalize, before preconditioning) and n in packed 'U' order, for UpperSymmPackMatrix.getData() */
+/* N (after finalize, before preconditioning) and n in packed 'U' order, for UpperSymmPackMatrix.getData().
+ * len = U(U+1)/2.  When the last accumulate pre-eliminated the exterior orientations (jaicov_neq_reduced_order() < U)
+ * the arrays hold the REDUCED system in their leading reduced_order() rows/columns (packed 'U': the leading
+ * k(k+1)/2 entries) and zeros elsewhere -- what reduceNormalEquationSystem (BA:1197-1340) leaves in N11, n1; call
+ * jaicov_neq_prepare_inverse(e, JAICOV_INVERT_FULL) before the build to obtain the unreduced N.                    */
 int jaicov_neq_get_normal(jaicov_engine *e, double *N_packed, size_t len, double *n, size_t U);
 /* Qxx (BA:1177 getCofactorMatrix), packed 'U', order jaicov_neq_cofactor_order().  Requires an inverting solve. */
 int jaicov_neq_get_cofactor(jaicov_engine *e, double *Q_packed, size_t len);
