@@ -55,26 +55,29 @@ __device__ __forceinline__ void chol16_inv(double *S, double *Wd_p, int c0, int 
         const double ljj = d * rl;
         rinv[j] = rl;
         a[j] = (l15 == j) ? ljj : a[j] * rl;
+        // column j of L goes to LDS; the next column, which the following step waits for, gets its multiplier by
+        // v_readlane (short latency), the other 14-j columns read theirs back from LDS as broadcast loads (pipelined)
+        if (lane < 16 && lane >= j) S[(c0 + lane) * DP + c0 + j] = a[j];
+        if (j + 1 < 16) a[j + 1] -= a[j] * bcast(a[j], j + 1);
 #pragma unroll
-        for (int k = j + 1; k < 16; k++) {
-            const double lkj = bcast(a[j], k);
-            a[k] -= a[j] * lkj;
-        }
+        for (int k = j + 2; k < 16; k++) a[k] -= a[j] * S[(c0 + k) * DP + c0 + j];
     }
-    // X = L^-1: lane c holds column c
+    // the factor is in LDS now: the inverse below reads L[i][k] from there as wave-uniform (broadcast) loads, which the
+    // hardware pipelines, instead of 120 v_readlane pairs on the scalar path
+    // X = L^-1 by forward substitution, lane c holds column c; column-oriented so that the 15-k updates that follow
+    // x[k] are independent of each other (the dependent chain is 16 links, not 120)
+    double sres[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        double sacc = (l15 == i) ? 1.0 : 0.0;
+    for (int i = 0; i < 16; i++) sres[i] = (l15 == i) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; k++) sacc -= bcast(a[k], i) * x[k];
-        x[i] = sacc * rinv[i];
+    for (int k = 0; k < 16; k++) {
+        x[k] = sres[k] * rinv[k];
+#pragma unroll
+        for (int i = k + 1; i < 16; i++) sres[i] -= S[(c0 + i) * DP + c0 + k] * x[k];
     }
     if (lane < 16) {
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            if (k <= lane) S[(c0 + lane) * DP + c0 + k] = a[k];
-            Wd_p[k * WDP + lane] = x[k];          // Wdd[row k][col lane]
-        }
+        for (int k = 0; k < 16; k++) Wd_p[k * WDP + lane] = x[k];          // Wdd[row k][col lane]
     }
 }
 
