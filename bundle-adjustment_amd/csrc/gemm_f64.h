@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -268,6 +269,7 @@ inline std::vector<int2> xcd_tile_map(int T) {
 // Launches that cannot give every CU two 128-tiles (the regime in which the 128-tile runs at its rate) take the
 // 64-tile latency variant; `small_tiles` < 0 = that rule, 0 = never, 1 = always (rectangular KMODE_FULL calls only).
 constexpr int GEMM_SMALL_TILE_LIMIT = 480;
+constexpr int GEMM_TINY_TILE_LIMIT = 256;   // 64-tiles below which the 32-tile variant is used
 inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1, int small_tiles = -1, int tag = 0) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const int tm = g.M / 128, tn = g.N / 128;
@@ -275,10 +277,22 @@ inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g,
     dim3 grid(g.tile_map ? g.n_map : tiles, batch), block(256);
     const bool can_small = !g.lower_only && g.kmode == KMODE_FULL && alay == LAY_KC && blay == LAY_KC;
     if (can_small && (small_tiles > 0 || (small_tiles < 0 && tiles * batch < GEMM_SMALL_TILE_LIMIT))) {
+        // even the 64-tile leaves most SIMDs idle when only a few block rows remain; a wave then spends its k-step in
+        // 16 dependent-issue MFMAs.  The 32-tile (one MFMA tile per wave) cuts that to 4.
+        static const int tiny_limit = getenv("JAICOV_TINY_LIMIT") ? atoi(getenv("JAICOV_TINY_LIMIT")) : GEMM_TINY_TILE_LIMIT;
+        const bool tiny = small_tiles < 0 && tiles * batch * 4 < tiny_limit;
         if (g.C == g.A || g.C == g.B) {   // in place (one column tile): keep the whole row of C in one workgroup
             if (tn != 1) return hipErrorInvalidValue;
-            grid.x = tiles * 2;
-            hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 128>), grid, block, 0, s, g);
+            if (tiny) {
+                grid.x = tiles * 4;
+                hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 32, 128>), grid, block, 0, s, g);
+            } else {
+                grid.x = tiles * 2;
+                hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 128>), grid, block, 0, s, g);
+            }
+        } else if (tiny) {
+            grid.x = tiles * 16;
+            hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 32, 32>), grid, block, 0, s, g);
         } else {
             grid.x = tiles * 4;
             hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 64>), grid, block, 0, s, g);
