@@ -476,7 +476,8 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
         // While the trailing update still hides the panel (many rows left) the panel GEMMs take the 128-tile: it costs
         // the update fewer CU slots per flop than the 64-tile latency variant, which is for the critical-path regime.
         static const int bulk_rows = getenv("JAICOV_BULK_ROWS") ? atoi(getenv("JAICOV_BULK_ROWS")) : 9216;
-        const int small = (st == pstream && rows_k > bulk_rows) ? 0 : -1;
+        // in between (the update still shares the chip) the 64-tile; the 32-tile only once the panel runs alone
+        const int small = (st == pstream && rows_k > bulk_rows) ? 0 : ((st == pstream && rows_k > tail_rows) ? 1 : -1);
         if (k > K0) {
             GemmArgs c{};
             c.A = L + (long)(k * 128) * ld + K0 * 128; c.lda = ld;      // L[k*128:n, K0*128 : k*128]
