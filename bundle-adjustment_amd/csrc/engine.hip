@@ -310,9 +310,11 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if (D->dist_kind[j] < D->dist_kind[j - 1]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "distortion coefficients must be in DistortionModel.Type order");
         // AffinityShearDistortionModel always owns Cx and Cy, TangentialDistortionModel Bx and By (+ optional Bi): a lone
         // member would silently drop out of the model (ASF:37-81, TDF:39-134 read both)
-        int cnt[7] = {0, 0, 0, 0, 0, 0, 0};
+        int cnt[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         for (int j = jb; j < je; j++) {
-            if (D->dist_kind[j] < 0 || D->dist_kind[j] > 6) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "unknown distortion coefficient kind");
+            if (D->dist_kind[j] < 0 || D->dist_kind[j] > JAICOV_DIST_ZERNIKE_Z) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "unknown distortion coefficient kind");
+            if (D->dist_kind[j] >= JAICOV_DIST_ZERNIKE_X && (D->dist_order[j] < 1 || D->dist_order[j] > 119))
+                FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "Zernike coefficient order must be 1..119 (ZernikeDistortionModel.java:67-68)");
             cnt[D->dist_kind[j]]++;
         }
         if (cnt[0] != cnt[1] || cnt[0] > 1 || cnt[2] != cnt[3] || cnt[2] > 1 || (cnt[4] > 0 && cnt[2] == 0))

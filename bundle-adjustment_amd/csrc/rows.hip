@@ -24,6 +24,15 @@ __device__ __forceinline__ void dmf_apply(RowAcc &a, double deltaX, double delta
     }
 }
 
+// MathExtension.binomial (MathExtension.java:53-64)
+__device__ __forceinline__ long zbinomial(int n, int k) {
+    if (k < 0 || k > n) return 0;
+    if (k > n - k) k = n - k;
+    long result = 1;
+    for (int i = 1; i <= k; i++) result = result * (n - k + i) / i;
+    return result;
+}
+
 __global__ __launch_bounds__(256) void rows_kernel(DevProblem p, const double *__restrict__ vals, int ip0, int count,
                                                    double *__restrict__ rowsA, double *__restrict__ rowsW) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -163,6 +172,64 @@ __global__ __launch_bounds__(256) void rows_kernel(DevProblem p, const double *_
             a.ax[l] += pN[l] * dXN;
             a.ay[l] += pN[l] * dYN;
         }
+    }
+    // ZernikeDistortionModelFactory.java:41-227: X, Y (ZDF:153-227), then Gradient (ZDF:41-143), literally -- including
+    // the integer division of the radial exponents (ZDF:107,176,178)
+    bool any_z = false;
+    for (int j = jb; j < je; j++) any_z = any_z || p.dist_kind[j] >= JAICOV_DIST_ZERNIKE_X;
+    if (any_z) {
+        const double xxs = xs * xs, yys = ys * ys, xys = xs * ys;
+        const double phi = atan2(ys, xs);
+        const double rn2 = r2 / r02;
+        const double const2rnr0 = 2.0 / rn2 / r02;
+        for (int kind = JAICOV_DIST_ZERNIKE_X; kind <= JAICOV_DIST_ZERNIKE_Z; kind++)
+            for (int j = jb; j < je; j++) {
+                if (p.dist_kind[j] != kind) continue;
+                const double zi = dv[j];
+                const int order = p.dist_order[j];
+                const int n = (int)ceil((-3.0 + sqrt(9.0 + 8.0 * order)) / 2.0);     // ZernikeCoefficient.java:43-44
+                const int mi = 2 * order - n * (n + 2);
+                const int halfnm = (n - abs(mi)) / 2;
+                const double length = sqrt((1 + ((mi != 0) ? 1 : 0)) * (n + 1) / 3.14159265358979323846);
+                const double m = mi;
+                double sinmphi, cosmphi;
+                sincos(m * phi, &sinmphi, &cosmphi);
+                double own_x = 0.0, own_y = 0.0;
+                for (int k = 0; k <= halfnm; k++) {
+                    const long pj = n - 2 * k;
+                    const double cj = length * (double)(((k % 2 == 0) ? 1 : -1) * zbinomial(n - k, k) * zbinomial(n - 2 * k, halfnm - k));
+                    const double cX = (mi < 0) ? (-pj * xs * sinmphi + m * ys * cosmphi) : (pj * xs * cosmphi + m * ys * sinmphi);
+                    const double cY = (mi < 0) ? (-pj * ys * sinmphi - m * xs * cosmphi) : (pj * ys * cosmphi - m * xs * sinmphi);
+                    if (kind != JAICOV_DIST_ZERNIKE_Z) {
+                        const double constC = cj * pow(rn2, (double)(pj / 2));
+                        const double constZ = zi * cj / r02 * pow(rn2, (double)(pj / 2 - 1));
+                        const double az = (mi < 0) ? -constC * sinmphi : constC * cosmphi;
+                        const double delta = zi * az;
+                        if (kind == JAICOV_DIST_ZERNIKE_X) { dmf_apply(a, delta, 0.0, constZ * cX, constZ * cY, 0.0, 0.0); own_x += az; }
+                        else { dmf_apply(a, 0.0, delta, 0.0, 0.0, constZ * cX, constZ * cY); own_y += az; }
+                    } else {
+                        const long ce = pj / 2 - 1;
+                        const double constC = cj / r02 * pow(rn2, (double)ce);
+                        double dXxs, dXys, dYxs, dYys;
+                        if (mi < 0) {
+                            dXxs = ce * xs * const2rnr0 * cX - pj * sinmphi + m / r2 * (pj * xys * cosmphi + m * yys * sinmphi);
+                            dXys = ce * ys * const2rnr0 * cX + m * cosmphi - m / r2 * (pj * xxs * cosmphi + m * xys * sinmphi);
+                            dYxs = ce * xs * const2rnr0 * cY - m * cosmphi + m / r2 * (pj * yys * cosmphi - m * xys * sinmphi);
+                            dYys = ce * ys * const2rnr0 * cY - pj * sinmphi - m / r2 * (pj * xys * cosmphi - m * xxs * sinmphi);
+                        } else {
+                            dXxs = ce * xs * const2rnr0 * cX + pj * cosmphi + m / r2 * (pj * xys * sinmphi - m * yys * cosmphi);
+                            dXys = ce * ys * const2rnr0 * cX + m * sinmphi - m / r2 * (pj * xxs * sinmphi - m * xys * cosmphi);
+                            dYxs = ce * xs * const2rnr0 * cY - m * sinmphi + m / r2 * (pj * yys * sinmphi + m * xys * cosmphi);
+                            dYys = ce * ys * const2rnr0 * cY + pj * cosmphi - m / r2 * (pj * xys * sinmphi + m * xxs * cosmphi);
+                        }
+                        const double zc = zi * constC;
+                        dmf_apply(a, zc * cX, zc * cY, zc * dXxs, zc * dXys, zc * dYxs, zc * dYys);
+                        own_x += constC * cX;
+                        own_y += constC * cY;
+                    }
+                }
+                OWN(j, own_x, own_y);
+            }
     }
 #undef OWN
     // ---- store the twelve base columns: X,Y,Z,x0,y0,c,X0,Y0,Z0,omega,phi,kappa -----------------------------

@@ -23,6 +23,8 @@ PYBIND11_MODULE(_jaicov_host, m) {
         .value("TANGENTIAL_DISTORTION_Bx", ParameterType::TANGENTIAL_DISTORTION_Bx).value("TANGENTIAL_DISTORTION_By", ParameterType::TANGENTIAL_DISTORTION_By)
         .value("AFFINITY_AND_SHEAR_Cx", ParameterType::AFFINITY_AND_SHEAR_Cx).value("AFFINITY_AND_SHEAR_Cy", ParameterType::AFFINITY_AND_SHEAR_Cy)
         .value("DISTANCE_POLYNOMIAL_D", ParameterType::DISTANCE_POLYNOMIAL_D)
+        .value("ZERNIKE_POLYNOMIAL_X", ParameterType::ZERNIKE_POLYNOMIAL_X).value("ZERNIKE_POLYNOMIAL_Y", ParameterType::ZERNIKE_POLYNOMIAL_Y)
+        .value("ZERNIKE_POLYNOMIAL_Z", ParameterType::ZERNIKE_POLYNOMIAL_Z)
         .value("CAMERA_COORDINATE_X", ParameterType::CAMERA_COORDINATE_X).value("CAMERA_COORDINATE_Y", ParameterType::CAMERA_COORDINATE_Y)
         .value("CAMERA_COORDINATE_Z", ParameterType::CAMERA_COORDINATE_Z).value("CAMERA_OMEGA", ParameterType::CAMERA_OMEGA)
         .value("CAMERA_PHI", ParameterType::CAMERA_PHI).value("CAMERA_KAPPA", ParameterType::CAMERA_KAPPA)
@@ -39,7 +41,9 @@ PYBIND11_MODULE(_jaicov_host, m) {
         .value("PRE_ELIMINATION", MatrixInversion::PRE_ELIMINATION).value("REDUCED", MatrixInversion::REDUCED);
     py::enum_<DistortionModel::Type>(m, "DistortionModelType")
         .value("AFFINITY_AND_SHEAR", DistortionModel::Type::AFFINITY_AND_SHEAR).value("TANGENTIAL_DISTORTION", DistortionModel::Type::TANGENTIAL_DISTORTION)
-        .value("RADIAL_DISTORTION", DistortionModel::Type::RADIAL_DISTORTION).value("DISTANCE_DISTORTION", DistortionModel::Type::DISTANCE_DISTORTION);
+        .value("RADIAL_DISTORTION", DistortionModel::Type::RADIAL_DISTORTION).value("DISTANCE_DISTORTION", DistortionModel::Type::DISTANCE_DISTORTION)
+        .value("ZERNIKE_X", DistortionModel::Type::ZERNIKE_X).value("ZERNIKE_Y", DistortionModel::Type::ZERNIKE_Y)
+        .value("ZERNIKE_GRADIENT", DistortionModel::Type::ZERNIKE_GRADIENT);
 
     py::class_<UnknownParameter>(m, "UnknownParameter")
         .def("getParameterType", &UnknownParameter::getParameterType)

@@ -209,7 +209,7 @@ void BundleAdjustment::flatten() {
     for (Camera *c : cameras_) {
         double r0 = 0.0;
         for (auto &m : c->getDistortionModels()) {
-            if (m->getType() == DistortionModel::Type::RADIAL_DISTORTION || m->getType() == DistortionModel::Type::DISTANCE_DISTORTION) r0 = m->getR0();
+            if (m->getType() >= DistortionModel::Type::RADIAL_DISTORTION) r0 = m->getR0();   // radial, distance, Zernike models carry r0
             for (auto &p : m->parameters()) {
                 int kind;
                 switch (p->getParameterType()) {
@@ -219,6 +219,9 @@ void BundleAdjustment::flatten() {
                 case ParameterType::TANGENTIAL_DISTORTION_By: kind = JAICOV_DIST_TANGENTIAL_BY; break;
                 case ParameterType::TANGENTIAL_POLYNOMIAL_B: kind = JAICOV_DIST_TANGENTIAL_BI; break;
                 case ParameterType::RADIAL_POLYNOMIAL_A: kind = JAICOV_DIST_RADIAL_AI; break;
+                case ParameterType::ZERNIKE_POLYNOMIAL_X: kind = JAICOV_DIST_ZERNIKE_X; break;
+                case ParameterType::ZERNIKE_POLYNOMIAL_Y: kind = JAICOV_DIST_ZERNIKE_Y; break;
+                case ParameterType::ZERNIKE_POLYNOMIAL_Z: kind = JAICOV_DIST_ZERNIKE_Z; break;
                 default: kind = JAICOV_DIST_DISTANCE_DI; break;
                 }
                 p->slot = (int)f.slot_param.size(); f.slot_param.push_back(p.get());

@@ -34,6 +34,7 @@ enum class ParameterType : int {
     PRINCIPAL_POINT_X = 111, PRINCIPAL_POINT_Y = 112, PRINCIPAL_DISTANCE = 113, RADIAL_POLYNOMIAL_A = 121,
     TANGENTIAL_POLYNOMIAL_B = 131, TANGENTIAL_DISTORTION_Bx = 132, TANGENTIAL_DISTORTION_By = 133,
     AFFINITY_AND_SHEAR_Cx = 141, AFFINITY_AND_SHEAR_Cy = 142, DISTANCE_POLYNOMIAL_D = 151,
+    ZERNIKE_POLYNOMIAL_X = 161, ZERNIKE_POLYNOMIAL_Y = 162, ZERNIKE_POLYNOMIAL_Z = 163,
     CAMERA_COORDINATE_X = 251, CAMERA_COORDINATE_Y = 252, CAMERA_COORDINATE_Z = 253,
     CAMERA_OMEGA = 261, CAMERA_PHI = 262, CAMERA_KAPPA = 263,
     OBJECT_COORDINATE_X = 311, OBJECT_COORDINATE_Y = 312, OBJECT_COORDINATE_Z = 313,
@@ -148,7 +149,9 @@ class DistortionModel {
 public:
     DistortionModel(const DistortionModel &) = delete;
     DistortionModel &operator=(const DistortionModel &) = delete;
-    enum class Type { AFFINITY_AND_SHEAR = 0, TANGENTIAL_DISTORTION = 1, RADIAL_DISTORTION = 2, DISTANCE_DISTORTION = 3 };
+    // DistortionModel.java:29-37 (ordinal = application order, Camera.java:50)
+    enum class Type { AFFINITY_AND_SHEAR = 0, TANGENTIAL_DISTORTION = 1, RADIAL_DISTORTION = 2, DISTANCE_DISTORTION = 3,
+                      ZERNIKE_X = 4, ZERNIKE_Y = 5, ZERNIKE_GRADIENT = 6 };
     DistortionModel(Type t, double r0) : type_(t), r0_(r0) {
         if (t == Type::AFFINITY_AND_SHEAR) {          // AffinityShearDistortionModel.java:34-40: Cx, Cy fixed by default
             params_.emplace_back(new UnknownParameter(ParameterType::AFFINITY_AND_SHEAR_Cx, this));
@@ -170,7 +173,10 @@ public:
             if (p->getOrder() == order) throw std::invalid_argument("Error, polynomial coefficient order already exists.");
         ParameterType pt = type_ == Type::TANGENTIAL_DISTORTION ? ParameterType::TANGENTIAL_POLYNOMIAL_B
                            : type_ == Type::RADIAL_DISTORTION   ? ParameterType::RADIAL_POLYNOMIAL_A
-                                                                : ParameterType::DISTANCE_POLYNOMIAL_D;
+                           : type_ == Type::DISTANCE_DISTORTION ? ParameterType::DISTANCE_POLYNOMIAL_D
+                           : type_ == Type::ZERNIKE_X           ? ParameterType::ZERNIKE_POLYNOMIAL_X      // ZernikeDistortionModel.java:36-38
+                           : type_ == Type::ZERNIKE_Y           ? ParameterType::ZERNIKE_POLYNOMIAL_Y      // :47-49
+                                                                : ParameterType::ZERNIKE_POLYNOMIAL_Z;     // :58-60
         params_.emplace_back(new UnknownParameter(pt, this, order));
         return params_.back().get();
     }

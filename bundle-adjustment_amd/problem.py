@@ -16,6 +16,7 @@ COL_FIXED = -1
 # jaicov_dist_kind (DistortionModel.Type application order, DistortionModel.java:29-37)
 DIST_AFFINITY_CX, DIST_AFFINITY_CY, DIST_TANGENTIAL_BX, DIST_TANGENTIAL_BY, DIST_TANGENTIAL_BI, DIST_RADIAL_AI, \
     DIST_DISTANCE_DI = range(7)
+DIST_ZERNIKE_X, DIST_ZERNIKE_Y, DIST_ZERNIKE_Z = 7, 8, 9   # ZernikeDistortionModel.X / .Y / .Gradient; order = Zernike index >= 1
 
 DATUM_TX, DATUM_TY, DATUM_TZ, DATUM_RX, DATUM_RY, DATUM_RZ, DATUM_SCALE = 1, 2, 4, 8, 16, 32, 64
 

@@ -62,7 +62,14 @@ typedef enum jaicov_dist_kind {
     JAICOV_DIST_TANGENTIAL_BY = 3,
     JAICOV_DIST_TANGENTIAL_BI = 4,
     JAICOV_DIST_RADIAL_AI     = 5,    /* RadiallySymmetricDistortionModel Ai (RSF:39-90)                */
-    JAICOV_DIST_DISTANCE_DI   = 6     /* RadialDistanceDistortionModel Di (RDF:39-161)                  */
+    JAICOV_DIST_DISTANCE_DI   = 6,    /* RadialDistanceDistortionModel Di (RDF:39-161)                  */
+    /* ZernikeDistortionModel.X / .Y / .Gradient (ZernikeDistortionModelFactory.java:41-227); dist_order = the single
+     * index `order` >= 1 of ZernikeCoefficient (n, m from Schwiegerling Eq. 2:100/101, ZernikeCoefficient.java:41-57).
+     * Restated literally, including the integer division `pj/2` of the radial exponents (ZDF:107,176,178): for odd
+     * radial orders the reference's value and its chain-rule factors are not derivatives of one another.          */
+    JAICOV_DIST_ZERNIKE_X     = 7,
+    JAICOV_DIST_ZERNIKE_Y     = 8,
+    JAICOV_DIST_ZERNIKE_Z     = 9
 } jaicov_dist_kind;
 
 /* Datum flags = which inner-constraint rows exist (RankDefect.java:119-130, BA:523-530 order).          */

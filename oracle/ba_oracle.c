@@ -138,6 +138,33 @@ static void dmf_apply(const colli_t *q, double A[2][ORA_KLOC], double w[2], doub
     }
 }
 
+#define ORA_ZMAX 16   /* radial terms of one Zernike polynomial */
+#define ORA_PI 3.14159265358979323846
+
+/* MathExtension.binomial (MathExtension.java:53-64) */
+static long binomial_ref(int n, int k) {
+    if (k < 0 || k > n) return 0;
+    if (k > n - k) k = n - k;
+    long result = 1;
+    for (int i = 1; i <= k; i++) result = result * (n - k + i) / i;
+    return result;
+}
+
+/* ZernikeCoefficient.ZernikePolynomial (ZernikeCoefficient.java:41-57): radial exponents p[], coefficients len*c[] */
+static int zernike_terms(int order, int *m_out, long p[ORA_ZMAX], double cn[ORA_ZMAX]) {
+    int n = (int)ceil((-3.0 + sqrt(9.0 + 8.0 * order)) / 2.0);
+    int m = 2 * order - n * (n + 2);
+    int halfnm = (n - abs(m)) / 2;
+    double length = sqrt((1 + ((m != 0) ? 1 : 0)) * (n + 1) / ORA_PI);
+    for (int k = 0; k <= halfnm && k < ORA_ZMAX; k++) {
+        p[k] = n - 2 * k;
+        long c = ((k % 2 == 0) ? 1 : -1) * binomial_ref(n - k, k) * binomial_ref(n - 2 * k, halfnm - k);
+        cn[k] = length * (double)c;
+    }
+    *m_out = m;
+    return halfnm + 1;
+}
+
 /*
  * PDF:285-445 getPartialDerivativeImageCoordinate without the stacking: fills the local 2 x KLOC row block, the
  * misclosure w and the 2x2 weight P (row-major; diag != 0 when rho == 0, PDF:300).  vals = slot vector.
@@ -264,6 +291,85 @@ static void eval_image_point(const jaicov_problem_desc *d, const double *vals, d
             A[0][l] += parN[l] * dXN;
             A[1][l] += parN[l] * dYN;
         }
+    }
+    /* ZernikeDistortionModelFactory.java:153-227 (X, then Y: DistortionModel.Type order) */
+    for (int kind = JAICOV_DIST_ZERNIKE_X; kind <= JAICOV_DIST_ZERNIKE_Y; kind++)
+        for (int j = jb; j < je; j++) {
+            if (d->dist_kind[j] != kind) continue;
+            double xxs = q.xs * q.xs, yys = q.ys * q.ys;
+            double phi = atan2(q.ys, q.xs);
+            double rr2 = xxs + yys, rn2 = rr2 / r02;
+            double zi = dv[j];
+            long p[ORA_ZMAX]; double cn[ORA_ZMAX]; int mi;
+            int nt = zernike_terms(d->dist_order[j], &mi, p, cn);
+            double m = mi, sinmphi = sin(m * phi), cosmphi = cos(m * phi);
+            double par_Zi = 0;
+            for (int t = 0; t < nt; t++) {
+                long pj = p[t];
+                double cj = cn[t];
+                double constC = cj * pow(rn2, (double)(pj / 2));
+                double constZ = zi * cj / r02 * pow(rn2, (double)(pj / 2 - 1));
+                double delta, par_delta_xs, par_delta_ys;
+                if (m < 0) {
+                    double constXsin = (-pj * q.xs * sinmphi + m * q.ys * cosmphi);
+                    double constYsin = (-pj * q.ys * sinmphi - m * q.xs * cosmphi);
+                    par_delta_xs = constZ * constXsin; par_delta_ys = constZ * constYsin;
+                    delta = -zi * constC * sinmphi;
+                    par_Zi += -constC * sinmphi;
+                } else {
+                    double constXcos = (pj * q.xs * cosmphi + m * q.ys * sinmphi);
+                    double constYcos = (pj * q.ys * cosmphi - m * q.xs * sinmphi);
+                    par_delta_xs = constZ * constXcos; par_delta_ys = constZ * constYcos;
+                    delta = +zi * constC * cosmphi;
+                    par_Zi += +constC * cosmphi;
+                }
+                if (kind == JAICOV_DIST_ZERNIKE_X) dmf_apply(&q, A, w, delta, 0, par_delta_xs, par_delta_ys, 0, 0);
+                else dmf_apply(&q, A, w, 0, delta, 0, 0, par_delta_xs, par_delta_ys);
+            }
+            if (kind == JAICOV_DIST_ZERNIKE_X) A[0][12 + j - jb] = par_Zi;
+            else A[1][12 + j - jb] = par_Zi;
+        }
+    /* ZernikeDistortionModelFactory.java:41-143 (Gradient) */
+    for (int j = jb; j < je; j++) {
+        if (d->dist_kind[j] != JAICOV_DIST_ZERNIKE_Z) continue;
+        double xs = q.xs, ys = q.ys;
+        double xxs = xs * xs, yys = ys * ys, xys = xs * ys;
+        double phi = atan2(ys, xs);
+        double rr2 = xxs + yys, rn2 = rr2 / r02;
+        double const2rnr0 = 2.0 / rn2 / r02;
+        double zi = dv[j];
+        long p[ORA_ZMAX]; double cn[ORA_ZMAX]; int mi;
+        int nt = zernike_terms(d->dist_order[j], &mi, p, cn);
+        double m = mi, sinmphi = sin(m * phi), cosmphi = cos(m * phi);
+        double par_xs_Zi = 0, par_ys_Zi = 0;
+        for (int t = 0; t < nt; t++) {
+            long pj = p[t];
+            long constExp = (pj / 2 - 1);
+            double cj = cn[t];
+            double constC = cj / r02 * pow(rn2, (double)constExp);
+            if (m < 0) {
+                double constXsin = (-pj * xs * sinmphi + m * ys * cosmphi);
+                double constYsin = (-pj * ys * sinmphi - m * xs * cosmphi);
+                double deltaX = zi * constC * constXsin, deltaY = zi * constC * constYsin;
+                double dXxs = zi * constC * (constExp * xs * const2rnr0 * constXsin - pj * sinmphi + m / rr2 * (pj * xys * cosmphi + m * yys * sinmphi));
+                double dXys = zi * constC * (constExp * ys * const2rnr0 * constXsin + m * cosmphi - m / rr2 * (pj * xxs * cosmphi + m * xys * sinmphi));
+                double dYxs = zi * constC * (constExp * xs * const2rnr0 * constYsin - m * cosmphi + m / rr2 * (pj * yys * cosmphi - m * xys * sinmphi));
+                double dYys = zi * constC * (constExp * ys * const2rnr0 * constYsin - pj * sinmphi - m / rr2 * (pj * xys * cosmphi - m * xxs * sinmphi));
+                dmf_apply(&q, A, w, deltaX, deltaY, dXxs, dXys, dYxs, dYys);
+                par_xs_Zi += constC * constXsin; par_ys_Zi += constC * constYsin;
+            } else {
+                double constXcos = (pj * xs * cosmphi + m * ys * sinmphi);
+                double constYcos = (pj * ys * cosmphi - m * xs * sinmphi);
+                double deltaX = zi * constC * constXcos, deltaY = zi * constC * constYcos;
+                double dXxs = zi * constC * (constExp * xs * const2rnr0 * constXcos + pj * cosmphi + m / rr2 * (pj * xys * sinmphi - m * yys * cosmphi));
+                double dXys = zi * constC * (constExp * ys * const2rnr0 * constXcos + m * sinmphi - m / rr2 * (pj * xxs * sinmphi - m * xys * cosmphi));
+                double dYxs = zi * constC * (constExp * xs * const2rnr0 * constYcos - m * sinmphi + m / rr2 * (pj * yys * sinmphi + m * xys * cosmphi));
+                double dYys = zi * constC * (constExp * ys * const2rnr0 * constYcos + pj * cosmphi - m / rr2 * (pj * xys * sinmphi + m * xxs * cosmphi));
+                dmf_apply(&q, A, w, deltaX, deltaY, dXxs, dXys, dYxs, dYys);
+                par_xs_Zi += constC * constXcos; par_ys_Zi += constC * constYcos;
+            }
+        }
+        A[0][12 + j - jb] = par_xs_Zi; A[1][12 + j - jb] = par_ys_Zi;
     }
 }
 

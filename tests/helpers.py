@@ -9,8 +9,8 @@ from bundle_adjustment_amd.problem import FlatProblem
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def load_golden_rows():
-    with open(os.path.join(GOLDEN, "jacobian_rows.json")) as fh:
+def load_golden_rows(name="jacobian_rows.json"):
+    with open(os.path.join(GOLDEN, name)) as fh:
         return json.load(fh)["sets"]
 
 

@@ -380,3 +380,68 @@ def test_config3_step_against_oracle(oracle_mod):
     dx = eng.solve(False)
     np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["zernike_x", "zernike_y", "zernike_gradient", "zernike_mixed"])
+def test_zernike_rows_match_golden_and_oracle(oracle_mod, name):
+    """Zernike X / Y / Gradient rows (ZernikeDistortionModelFactory.java:41-227) of the HIP kernel vs the oracle and vs the
+    symbolic golden vectors (even radial orders)."""
+    sets = helpers.load_golden_rows("jacobian_rows_zernike.json")
+    dist, cases = sets[name]["dist"], sets[name]["cases"]
+    fp = helpers.problem_from_cases(dist, cases)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    w, A = eng.get_rows(0, fp.n_image_points)
+    o = oracle_mod.Oracle(fp)
+    nd = len(dist)
+    for i, c in enumerate(cases):
+        wo, Ao, _, _ = o.rows(fp.values, i)
+        np.testing.assert_allclose(w[i], wo, rtol=0, atol=1e-13)
+        scale = np.abs(Ao[:, :12 + nd]).max(axis=1, keepdims=True)
+        assert (np.abs(A[i, :, :12 + nd] - Ao[:, :12 + nd]) / np.maximum(np.abs(Ao[:, :12 + nd]), 1e-6 * scale)).max() < 1e-10
+        for r, key in enumerate(("Ax", "Ay")):
+            ref = np.array(c[key])
+            assert (np.abs(A[i, r, :12 + nd] - ref) / np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())).max() < 1e-9
+    eng.close()
+
+
+def test_zernike_odd_orders_and_adjustment_match_oracle(oracle_mod):
+    """Odd radial orders have no independent truth (the reference truncates their exponents, ZDF:107,176,178): kernel and
+    oracle restate the same formulas and must agree with each other -- rows, normal equations and the step of a small
+    adjustment whose camera carries one coefficient of every Zernike model next to the radial set."""
+    from bundle_adjustment_amd.problem import DIST_ZERNIKE_X, DIST_ZERNIKE_Y, DIST_ZERNIKE_Z
+    import dataclasses
+    from test_gpu_edge_cases import renumber
+    base = scene.make_scene(8, 60, 40, dist=scene.DIST_RADIAL, weights="block", n_control=5, control_dense=True)
+    extra = [(DIST_ZERNIKE_X, 1, 2e-4), (DIST_ZERNIKE_X, 7, -1e-4), (DIST_ZERNIKE_Y, 2, 1e-4), (DIST_ZERNIKE_Y, 12, 5e-5),
+             (DIST_ZERNIKE_Z, 6, 1e-4), (DIST_ZERNIKE_Z, 13, -5e-5)]
+    nd = base.dist_kind.size
+    s = 3 * base.n_points + 3 + nd
+    fp = renumber(base, cam_dist_begin=np.array([0, nd + len(extra)], np.int32),
+                  dist_kind=np.concatenate([base.dist_kind, [k for k, _, _ in extra]]).astype(np.int32),
+                  dist_order=np.concatenate([base.dist_order, [o for _, o, _ in extra]]).astype(np.int32),
+                  values=np.concatenate([base.values[:s], [v for _, _, v in extra], base.values[s:]]), truth=None)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    U = fp.n_unknowns
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    w, A = eng.get_rows(0, 40)
+    k = 12 + nd + len(extra)
+    for i in range(40):
+        wo, Ao, _, _ = o.rows(fp.values, i)
+        np.testing.assert_allclose(w[i], wo, rtol=0, atol=1e-13)
+        scale = np.abs(Ao[:, :k]).max(axis=1, keepdims=True)
+        assert (np.abs(A[i, :, :k] - Ao[:, :k]) / np.maximum(np.abs(Ao[:, :k]), 1e-6 * scale)).max() < 1e-10
+    No, no, _ = o.build(fp.values, s2, 0.0)
+    dxo, _, _, _ = o.step(fp.values, s2, 0.0, False)
+    eng.prepare_inverse(engine.INVERT_FULL)
+    eng.build(s2, 0.0)
+    N, n = eng.get_normal()
+    Nf, Nof = packed_to_full(N, U), packed_to_full(No, U)
+    dg = np.sqrt(np.abs(np.diag(Nof))); dg[dg == 0] = 1.0
+    assert (np.abs(Nf - Nof) / np.outer(dg, dg)).max() < 1e-10
+    eng.prepare_inverse(engine.INVERT_NONE)
+    eng.build(s2, 0.0)
+    np.testing.assert_allclose(eng.solve(False), dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
+    eng.close()

@@ -221,3 +221,35 @@ def test_example_reduced_inversion_modes(H, example_base, mode):
     n = k * (k + 1) // 2
     ref = res["FULL"][1][:n]
     np.testing.assert_allclose(res[mode][1][:n], ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())   # two runs: atomics reorder sums
+
+
+def test_zernike_models_in_the_object_api(H):
+    """Camera with the three Zernike models next to the radial one (Camera.java:45-83 sorts the model types, DistortionModel
+    ordinal = application order; ZernikeDistortionModel.java:36-60 parameter types): columns and flat descriptor."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    from bundle_adjustment_amd.problem import DIST_RADIAL_AI, DIST_ZERNIKE_X, DIST_ZERNIKE_Y, DIST_ZERNIKE_Z
+    T, PT = H.DistortionModelType, H.ParameterType
+    cam = H.Camera(1, 13.488, [T.ZERNIKE_GRADIENT, T.RADIAL_DISTORTION, T.ZERNIKE_Y, T.ZERNIKE_X])   # any order: sorted
+    cam.getDistortionModel(T.RADIAL_DISTORTION).add(1)
+    zx, zy, zz = (cam.getDistortionModel(t) for t in (T.ZERNIKE_X, T.ZERNIKE_Y, T.ZERNIKE_GRADIENT))
+    assert zx.add(4).getParameterType() == PT.ZERNIKE_POLYNOMIAL_X
+    zx.add(7); zy.add(12); zz.add(3)
+    assert zz.get(3).getParameterType() == PT.ZERNIKE_POLYNOMIAL_Z and zy.get(12).getParameterType() == PT.ZERNIKE_POLYNOMIAL_Y
+    with pytest.raises(Exception):
+        zx.add(4)                                    # order exists already (PolynomialDistortionModel.java:60-62)
+    with pytest.raises(Exception):
+        zy.add(0)                                    # ZernikeDistortionModel.java:67-68
+    rng = np.random.default_rng(1)
+    pts = [H.ObjectCoordinate(str(i), *rng.normal(0, 100, 3)) for i in range(6)]
+    for i in range(3):
+        im = cam.add(i)
+        for p in pts:
+            im.add(p, 0.1 * i, 0.2, 0.001, 0.001)
+    ba = H.BundleAdjustment(); ba.add(cam)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba)
+    assert list(fp.dist_kind) == [DIST_RADIAL_AI, DIST_ZERNIKE_X, DIST_ZERNIKE_X, DIST_ZERNIKE_Y, DIST_ZERNIKE_Z]
+    assert list(fp.dist_order) == [1, 4, 7, 12, 3]
+    d = fp.rank_defect
+    # columns: 18 point coordinates, then x0, y0, c, then the five coefficients in model order, then the EO blocks
+    assert list(fp.dist_col) == [d + 18 + 3 + j for j in range(5)] and fp.cam_r0[0] == 13.488

@@ -39,6 +39,42 @@ def test_rows_match_symbolic_golden(oracle_mod, name):
     assert worst < 1e-10, worst
 
 
+@pytest.mark.parametrize("name", ["zernike_x", "zernike_y", "zernike_gradient", "zernike_mixed"])
+def test_zernike_rows_match_symbolic_golden(oracle_mod, name):
+    """ZernikeDistortionModelFactory.java:41-227 restated in the oracle vs sympy/mpmath derivatives of
+    dx = z Z(xs, ys) (X), dy = z Z (Y), (dx, dy) = z grad Z (Gradient) for polynomials of even radial order
+    (tests/golden/make_zernike_golden.py explains why only those have an independent truth)."""
+    sets = helpers.load_golden_rows("jacobian_rows_zernike.json")
+    dist, cases = sets[name]["dist"], sets[name]["cases"]
+    fp = helpers.problem_from_cases(dist, cases)
+    o = oracle_mod.Oracle(fp)
+    nd = len(dist)
+    worst = 0.0
+    for i, c in enumerate(cases):
+        w, A, P, diag = o.rows(fp.values, i)
+        np.testing.assert_allclose(w, c["w"], rtol=0, atol=1e-12)
+        for r, key in enumerate(("Ax", "Ay")):
+            ref = np.array(c[key])
+            err = np.abs(A[r, :12 + nd] - ref) / np.maximum(np.abs(ref), 1e-6 * np.abs(ref).max())
+            worst = max(worst, err.max())
+    assert worst < 1e-9, worst
+
+
+def test_zernike_polynomial_terms(oracle_mod):
+    """n, m of the single index (Schwiegerling Eq. 2:100/101) and Z_4^0 = sqrt(5/pi) (6 r^4 - 6 r^2 + 1) through the own
+    column of a ZERNIKE_X coefficient (= Z itself, ZDF:213-220)."""
+    sets = helpers.load_golden_rows("jacobian_rows_zernike.json")
+    case = sets["zernike_x"]["cases"][0]
+    fp = helpers.problem_from_cases([[7, 12]], [dict(case, dist_values=[0.0])])
+    w, A, _, _ = oracle_mod.Oracle(fp).rows(fp.values, 0)
+    # undistorted image coordinates: with z = 0 the residual is obs - (x0 + xs)
+    xs = case["obs"][0] - w[0] - case["io"][0]
+    ys = case["obs"][1] - w[1] - case["io"][1]
+    rho2 = (xs * xs + ys * ys) / case["r0"] ** 2
+    Z40 = np.sqrt(5.0 / np.pi) * (6.0 * rho2 ** 2 - 6.0 * rho2 + 1.0)
+    assert abs(A[0, 12] - Z40) < 1e-13 * max(1.0, abs(Z40)) and A[1, 12] == 0.0
+
+
 def test_weights_2x2(oracle_mod):
     sets = helpers.load_golden_rows()
     fp = helpers.problem_from_cases(sets["radial"]["dist"], sets["radial"]["cases"], sigma=7e-4, rho=0.3)
