@@ -800,6 +800,8 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
         const size_t len = (size_t)Ua * (Ua + 1) / 2;
         hipLaunchKernelGGL(unpack_kernel, dim3((Ua + 255) / 256, std::max(Ua, 1)), dim3(256), 0, e->stream, e->d_packed, (long)e->Upad, Ua, e->d_N);
         HIPE(e, hipMemcpyAsync(e->d_n, e->d_packed + len, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+        if (e->schur_active)   // what the EO elimination took from the diagonal, summed over the ranks like N itself (LM damping)
+            HIPE(e, hipMemcpyAsync(e->sb.diagcorr, e->d_packed + len + Ua, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
         e->reduced = false;
     }
     if (e->schur_active && lambda != e->lambda_acc && (lambda > 0 || e->lambda_acc > 0))
@@ -854,15 +856,18 @@ static int reduce_buffer_impl(jaicov_engine *e, void **device_ptr, size_t *count
     const int Ua = e->schur_active ? e->e0 : e->U;
     const size_t len = (size_t)Ua * (Ua + 1) / 2;
     if (!e->d_packed) {
-        int rc = dalloc(e, (size_t)e->U * (e->U + 1) / 2 + e->U, &e->d_packed);
+        int rc = dalloc(e, (size_t)e->U * (e->U + 1) / 2 + 2 * (size_t)e->U, &e->d_packed);
         if (rc) return rc;
     }
     hipLaunchKernelGGL(pack_kernel, dim3((Ua + 255) / 256, std::max(Ua, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, Ua, e->d_packed);
     HIPE(e, hipMemcpyAsync(e->d_packed + len, e->d_n, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    // with the EO pre-elimination the LM damping needs diag(N) - diag(N_reduced), also a sum over the ranks' images
+    if (e->schur_active)
+        HIPE(e, hipMemcpyAsync(e->d_packed + len + Ua, e->sb.diagcorr, (size_t)Ua * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
     if (sync) HIPE(e, hipStreamSynchronize(e->stream));   // the caller's collective runs on its own stream
     e->reduced = true;
     *device_ptr = e->d_packed;
-    *count = len + Ua;
+    *count = len + Ua + (e->schur_active ? (size_t)Ua : 0);
     return JAICOV_OK;
 }
 

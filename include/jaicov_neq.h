@@ -205,7 +205,8 @@ int jaicov_neq_reduced_order(const jaicov_engine *e);
 int jaicov_neq_finalize(jaicov_engine *e, double sigma2apriori, double lambda, int simulation);
 
 /* Device buffer holding this rank's partial normal equations between accumulate and finalize: one contiguous
- * array of *count = U(U+1)/2 + U doubles (N packed 'U' followed by n).  A multi-GPU host sums it over ranks in place
+ * array of *count doubles: N packed 'U' (k(k+1)/2, k = jaicov_neq_reduced_order()) followed by n (k) and, when the
+ * exterior orientations were pre-eliminated, by the k diagonal corrections the LM damping needs.  A multi-GPU host sums it over ranks in place
  * (ncclAllReduce, sum, double -- SURVEY 8(e)); finalize() picks the summed values up again.  The call synchronises
  * the engine stream so that the collective may run on any other stream.                                          */
 int jaicov_neq_reduce_buffer(jaicov_engine *e, void **device_ptr, size_t *count);

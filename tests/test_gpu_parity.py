@@ -445,3 +445,37 @@ def test_zernike_odd_orders_and_adjustment_match_oracle(oracle_mod):
     eng.build(s2, 0.0)
     np.testing.assert_allclose(eng.solve(False), dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
     eng.close()
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_sharded_reduce_buffers_with_damping(oracle_mod, lam):
+    """Two engines over disjoint image ranges, summed through their reduce buffers as the multi-GPU host does (here both on
+    one GPU, summed with torch): with the EO pre-elimination the buffer also carries the diagonal corrections of the LM
+    damping (BA:814-822 damps the UNREDUCED diagonal), so the damped step must equal the oracle's."""
+    import torch
+    from bundle_adjustment_amd.distributed import DeviceArray
+    fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    s2 = fp.sigma2apriori
+    dxo, _, _, _ = oracle_mod.Oracle(fp).step(fp.values, s2, lam, False)
+    a = engine.Engine(fp, image_range=(0, 3), apply_shared=True)
+    b = engine.Engine(fp, image_range=(3, fp.n_images), apply_shared=False)
+    bufs = []
+    for e_ in (a, b):
+        e_.set_parameters(fp.values)
+        e_.accumulate(s2, lam)
+        ptr, cnt = e_.reduce_buffer()
+        bufs.append(torch.as_tensor(DeviceArray(ptr, cnt), device="cuda:0"))
+    e0 = a.reduced_order()
+    assert bufs[0].numel() == e0 * (e0 + 1) // 2 + 2 * e0
+    total = bufs[0] + bufs[1]
+    bufs[0].copy_(total); bufs[1].copy_(total)
+    torch.cuda.synchronize()
+    dx = np.zeros(fp.n_unknowns)
+    for e_ in (a, b):
+        e_.finalize(s2, lam)
+        part = e_.solve(False)
+        np.testing.assert_allclose(part[:e0], dxo[:e0], rtol=0, atol=1e-9 * np.abs(dxo).max())
+        dx[:e0] = part[:e0]
+        dx[e0:] += part[e0:]                       # every engine returns its own images' EO step
+    np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    a.close(); b.close()
