@@ -214,12 +214,12 @@ def main():
                 eng.prepare_inverse(engine.INVERT_FULL)
                 eng.build(s2, 0.0)
                 dx = eng.solve(engine.INVERT_FULL)
-            om = eng.omega(s2, dx) if rank == 0 else 0.0
+            om = distributed.sharded_omega(eng, dist, torch.device("cuda", local), s2, dx) if use_dist else eng.omega(s2, dx)
             sync()
             if rank == 0:
                 out["final_pass_ms" if rep else "final_pass_first_call_ms"] = 1e3 * (time.perf_counter() - t1)
                 out["final_pass_stage_ms"] = eng.timings()
-                out["sigma0_ratio"] = om / fp.degree_of_freedom / s2 if world == 1 else None
+                out["sigma0_ratio"] = om / fp.degree_of_freedom / s2
         # final pass of MatrixInversion.REDUCED / PRE_ELIMINATION (BA:261-267): cofactor matrix of the border, points,
         # interior orientation and distortion only = inverse of the EO-reduced system (the second run is reported,
         # the first one allocates the inverse's buffers)

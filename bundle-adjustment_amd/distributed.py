@@ -86,3 +86,12 @@ def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
         dist.all_reduce(t)
         dx[e0:] = t.cpu().numpy()
     return dx
+
+
+def sharded_omega(eng, dist, device, sigma2, dx):
+    """Omega = sum over ALL observation groups of (w - A dx)' P (w - A dx) (BA:472-491): every rank evaluates its own images
+    (rank 0 also the scale bars and directly observed groups), the scalars are summed."""
+    import torch
+    t = torch.tensor([eng.omega(sigma2, dx)], dtype=torch.float64, device=device)
+    dist.all_reduce(t)
+    return float(t.item())
