@@ -1,0 +1,60 @@
+"""The N > 1 path end to end with two ranks on ONE GPU: two processes, each with its own engine over its image range, the
+reduce buffers summed by torch.distributed (backend gloo: device tensors staged through the host; RCCL refuses two ranks
+on one device).  Everything except the transport is what runs on 8 GPUs: partition, accumulate, reduce buffer (incl. the
+LM diagonal corrections), finalize, replicated solve, EO slice exchange, summed Omega."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _scene():
+    from bundle_adjustment_amd import scene
+    return scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT,):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    from bundle_adjustment_amd import distributed, engine
+    fp = _scene()
+    lo, hi = distributed.partition_images(fp, world)[rank]
+    eng = engine.Engine(fp, image_range=(lo, hi), apply_shared=(rank == 0))
+    eng.set_parameters(fp.values)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    res = []
+    for lam in (0.0, 0.5):
+        dx = distributed.sharded_step(eng, dist, dev, fp.sigma2apriori, lam)
+        res += [dx, [distributed.sharded_omega(eng, dist, dev, fp.sigma2apriori, dx)]]
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.concatenate(res))
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle_mod):
+    import torch.multiprocessing as mp
+    port = 29700 + (os.getpid() % 200)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    fp = _scene()
+    U = fp.n_unknowns
+    r0, r1 = np.load(tmp_path / "r0.npy"), np.load(tmp_path / "r1.npy")
+    np.testing.assert_array_equal(r0, r1)                      # replicated solve + exchanged EO slice: identical on both ranks
+    o = oracle_mod.Oracle(fp)
+    for i, lam in enumerate((0.0, 0.5)):
+        dxo, _, _, _ = o.step(fp.values, fp.sigma2apriori, lam, False)
+        base = i * (U + 1)
+        np.testing.assert_allclose(r0[base:base + U], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+        omo = o.omega(fp.values, fp.sigma2apriori, dxo)
+        assert abs(r0[base + U] - omo) <= 1e-9 * omo
