@@ -55,8 +55,10 @@ def allreduce_engine_buffer(eng, dist, device):
     waits for the pack kernel through stream events, the engine's finalize waits for RCCL the same way), so the host never
     blocks and the factorisation's launches are queued while assembly and collective still run.  gloo (CPU rehearsal)
     needs host tensors and takes the synchronous route."""
+    import os
     import torch
-    if device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl":
+    if (device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl"
+            and not os.environ.get("JAICOV_SYNC_COLLECTIVE")):      # the switch forces the host-synchronised route
         ptr, cnt, stream = eng.reduce_buffer_async()
         ext = torch.cuda.ExternalStream(stream, device=device)
         with torch.cuda.stream(ext):
