@@ -24,7 +24,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # AMD's public MI355X fp64 matrix (= fp64 vector) peak; the local microarch guide lists
-                               # no fp64 row.  bench also reports the measured issue-rate ceiling (peak_measured).
+                               # no fp64 row.  bench also reports the measured issue-rate ceiling (roofline.peak_measured).
 
 
 def parse():
@@ -196,6 +196,20 @@ def main():
             out["assembly_roofline"] = {"bound": "hbm", "achieved": abytes / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0,
                                         "peak": 8000.0, "unit": "GB/s", "frac": abytes / (asm_ms * 1e-3) / 1e9 / 8000.0 if asm_ms > 0 else 0.0,
                                         "algorithmic_bytes_per_pass": abytes, "stage_ms": asm_ms}
+        # measured issue ceiling of v_mfma_f64_16x16x4_f64 on this device (back-to-back independent MFMAs in registers):
+        # constant operands / random operands (the chip is power-limited on fp64 MFMA, the two differ)
+        try:
+            import ctypes as C
+            L = engine.load_library()
+            L.jaicov_debug_mfma_peak.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+            meas = []
+            for iters in (20000, -20000):
+                ms_, tf_ = C.c_double(), C.c_double()
+                L.jaicov_debug_mfma_peak(2048, iters, C.byref(ms_), C.byref(tf_))
+                meas.append(tf_.value)
+            out["roofline"]["peak_measured"] = {"constant_operands": meas[0], "random_operands": meas[1], "unit": "TFLOP/s"}
+        except Exception:
+            pass
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
