@@ -253,3 +253,30 @@ def test_zernike_models_in_the_object_api(H):
     d = fp.rank_defect
     # columns: 18 point coordinates, then x0, y0, c, then the five coefficients in model order, then the EO blocks
     assert list(fp.dist_col) == [d + 18 + 3 + j for j in range(5)] and fp.cam_r0[0] == 13.488
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["FULL", "REDUCED"])
+def test_native_example_program(example_base, mode):
+    """bundle-adjustment_amd/host/example_flatfiles: the reference's ExampleFlatFiles as a native program on the engine (C++
+    host mirror + C ABI, no Python in the loop): known answers of the bundled block (example.htm:31,33-35,42)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bundle-adjustment_amd", "host", "example_flatfiles")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "example_flatfiles"])
+    out = subprocess.run([exe, example_base, mode], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    kv = {}
+    for line in out.stdout.splitlines():
+        parts = line.split()
+        if len(parts) >= 2:
+            kv[" ".join(parts[:-1])] = parts[-1]
+    assert kv["observations"] == "19945" and kv["unknown parameters"] == "1147"
+    assert kv["datum conditions"] == "6" and kv["degree of freedom"] == "18804"
+    # sigma0^2 a-priori = the smallest observation variance (BA:98,641), and the .phc file carries AICON's per-point sigmas:
+    # sigma0 a-posteriori comes out at 1.2e-4; with the protocol's uniform a-priori sigma the oracle test above reproduces
+    # AICON's 0.000405
+    assert 5e-5 < float(kv["sigma0 a-posteriori"]) < 5e-4
+    assert kv["iterations"] == "4"
+    assert "ERROR_FREE_ESTIMATION" in out.stdout and "Estimation time" in out.stdout
