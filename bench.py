@@ -268,7 +268,7 @@ def main():
         de.close()
         ach = ks2["dense_flops"] / (ks2["dense_gemm_ms"] * 1e-3) / 1e12 if ks2["dense_gemm_ms"] > 0 else 0.0
         out["jtwj_dense_mode"] = {
-            "kernel": "gemm_f64_kernel<KC,XC> (B = P A) + gemm_f64_kernel<XC,XC> (S = A'B, lower), batches of 16 images",
+            "kernel": "gemm_f64_kernel<KC,XC> (B = P A) + gemm_f64_kernel<XC,XC> (S = A'B, lower), batched over all images of the pass",
             "bound": "mfma", "achieved": ach, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
             "gemm_ms_per_pass": ks2["dense_gemm_ms"], "assembly_ms_per_pass": wall,
             "algorithmic_flops_per_pass": ks2["dense_flops"],

@@ -10,6 +10,7 @@
 // The structure-aware path (assemble.hip, schur.hip) computes the same sums with ~2 % of the arithmetic because A_g has
 // 3 + kc non-zeros per row; this mode exists to measure "J'WJ MFMA utilisation" (BASELINE.json) and as an independent
 // second path for the parity tests.  The EO pre-elimination is off in this mode (the full system is assembled).
+#include <cstdlib>
 #include "ba_kernels.h"
 #include "gemm_f32.h"
 #include "gemm_f64.h"
@@ -92,8 +93,16 @@ hipError_t DenseMode::init(int max_m, int max_k1, int n_blocks, bool single) {
     fp32 = single;
     mpad = ((max_m + 127) / 128) * 128;
     kpad = ((max_k1 + 127) / 128) * 128;
-    batch = n_blocks < 16 ? (n_blocks > 0 ? n_blocks : 1) : 16;
+    // images per launch: the lower-triangular S launch has 78 tiles per image at config 4, so a small batch leaves
+    // the last of its ceil(78*batch/512) rounds of workgroups partly empty (batch 16: 2.44 rounds -> 3)
+    // and a large one amortises it: 55.4 TFLOP/s at 16, 60.7 at 32, 62.8 at 500 (scripts/dm_batch_sweep.py).
+    // Default: as many images as fit 32 GB of workspace (all 500 of config 4: 26 GB of the 288 GB).
     const size_t es = fp32 ? sizeof(float) : sizeof(double);
+    const size_t per_image = ((size_t)mpad * mpad + 2 * (size_t)mpad * kpad + (size_t)kpad * kpad) * es;
+    long want = (long)(((size_t)32 << 30) / per_image);
+    if (want < 1) want = 1;
+    if (const char *e = getenv("JAICOV_DM_BATCH")) want = atoi(e) > 0 ? atoi(e) : want;
+    batch = n_blocks < want ? (n_blocks > 0 ? n_blocks : 1) : (int)want;
     hipError_t he;
     if ((he = hipMalloc(&Ppad, (size_t)batch * mpad * mpad * es)) != hipSuccess) return he;
     if ((he = hipMalloc(&Apad, (size_t)batch * mpad * kpad * es)) != hipSuccess) return he;

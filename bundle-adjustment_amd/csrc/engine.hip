@@ -1364,13 +1364,22 @@ extern "C" int jaicov_debug_gemm_trace(int M, int K, int lower_only, long long *
     const int tm = M / 128, tiles = lower_only ? tm * (tm + 1) / 2 : tm * tm;
     double *dA = nullptr, *dC = nullptr; long long *dT = nullptr;
     hipMalloc(&dA, (size_t)M * K * 8); hipMalloc(&dC, (size_t)M * M * 8); hipMalloc(&dT, (size_t)tiles * 64);
-    hipMemset(dA, 0, (size_t)M * K * 8); hipMemset(dC, 0, (size_t)M * M * 8); hipMemset(dT, 0, (size_t)tiles * 64);
+    hipMemset(dC, 0, (size_t)M * M * 8); hipMemset(dT, 0, (size_t)tiles * 64);
+    {   // random operands (the matrix pipe draws more power on them than on zeros) and a warm chip
+        std::vector<double> h((size_t)M * K);
+        uint64_t x = 88172645463325252ull;
+        for (auto &v : h) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5; }
+        hipMemcpy(dA, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    }
     GemmArgs g{};
     g.A = dA; g.B = dA; g.C = dC; g.lda = K; g.ldb = K; g.ldc = M; g.M = M; g.N = M; g.K = K;
-    g.alpha = -1.0; g.beta = 1.0; g.lower_only = lower_only; g.kmode = KMODE_FULL;
-    gemm_f64(nullptr, LAY_KC, LAY_KC, g);
+    g.alpha = -1e-3; g.beta = 1.0; g.lower_only = lower_only; g.kmode = KMODE_FULL;
+    int warm = 40;
+    if (const char *e = getenv("JAICOV_TRACE_WARM")) warm = atoi(e);
+    const int tag = getenv("JAICOV_TRACE_TAG") ? atoi(getenv("JAICOV_TRACE_TAG")) : 0;
+    for (int i = 0; i < warm; i++) gemm_f64(nullptr, LAY_KC, LAY_KC, g, 1, 0, tag);
     g.trace = dT;
-    hipError_t he = gemm_f64(nullptr, LAY_KC, LAY_KC, g);
+    hipError_t he = gemm_f64(nullptr, LAY_KC, LAY_KC, g, 1, 0, tag);
     he = he == hipSuccess ? hipDeviceSynchronize() : he;
     hipMemcpy(out, dT, (size_t)tiles * 64, hipMemcpyDeviceToHost);
     hipFree(dA); hipFree(dC); hipFree(dT);

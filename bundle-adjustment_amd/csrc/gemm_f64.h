@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
             tile_col = t - tile_row * tn;
         }
     }
-    long long t_start = 0, t_loop0 = 0, t_loop1 = 0;
+    long long t_start = 0, t_loop0 = 0, t_loop1 = 0, c_loop0 = 0;
     if (g.trace) t_start = wall_clock64();
     const long m0 = (long)tile_row * GEMM_BM, n0 = (long)tile_col * GEMM_BN;
     int kbeg = 0, kend = g.K;
@@ -98,35 +98,46 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
     const double *ap, *bp;
     long astep, bstep;
     int a_lds, b_lds;  // LDS element offset of this thread's first element
+    // Operand in KC layout (k contiguous in memory): 8 lanes fetch one 128-byte line = the 16 k of one row, so a wave
+    // instruction touches 8 lines.  (One lane per row, 64 lines per instruction, kept the L1's address path busy for
+    // the whole k-step: the loop ran 10 % faster with its global loads removed, and equally fast with this pattern.)
+    // The thread's pair (k = 2 seg, 2 seg + 1) goes to LDS rows 2 seg + (seg & 1) and the other one of the pair, at
+    // column row + 8 (seg >> 1 & 1) + 4 (seg >> 2): the 32 lanes of a half-wave (8 seg x 4 rows) then hit the 32
+    // double-wide banks 16 (seg & 1) + 8 (seg >> 1 & 1) + 4 (seg >> 2) + row % 4 once each.  The k order inside a block
+    // of 4 is free as long as A and B agree (ksw), and the column shift is the same for the 4 LDS rows of one MFMA
+    // k-block (8 (ks & 1) + 4 (ks >> 1) below), so the fragment reads keep compile-time offsets.
+    const int seg = tid & 7, rbase = tid >> 3;
+    const int a_odd = (seg & 1) * LDA_S, b_odd = (seg & 1) * LDB_S;   // x (k = 2 seg) goes to LDS row 2 seg + (seg & 1), y to the other
+    auto ksw = [](int k) { return (k & ~1) | ((k ^ (k >> 1)) & 1); };   // LDS row of k-in-tile
     if (ALAY == LAY_KC) {
-        const int row = tid & (TM - 1), kh = tid / TM;
-        ap = A + (m0 + row) * g.lda + kbeg + EPA * kh;
+        ap = A + (m0 + rbase) * g.lda + kbeg + 2 * seg;
         astep = GEMM_BK;
-        a_lds = (EPA * kh) * LDA_S + row;
+        a_lds = (2 * seg) * LDA_S + rbase + 8 * ((seg >> 1) & 1) + 4 * (seg >> 2);
     } else {
         const int kr = tid >> 4, ms = tid & 15;
         ap = A + (long)(kbeg + kr) * g.lda + m0 + EPA * ms;
         astep = (long)GEMM_BK * g.lda;
-        a_lds = kr * LDA_S + EPA * ms;
+        a_lds = ksw(kr) * LDA_S + EPA * ms;
     }
     if (BLAY == LAY_KC) {
-        const int row = tid & (TN - 1), kh = tid / TN;
-        bp = B + (n0 + row) * g.ldb + kbeg + EPB * kh;
+        bp = B + (n0 + rbase) * g.ldb + kbeg + 2 * seg;
         bstep = GEMM_BK;
-        b_lds = (EPB * kh) * LDB_S + row;
+        b_lds = (2 * seg) * LDB_S + rbase + 8 * ((seg >> 1) & 1) + 4 * (seg >> 2);
     } else {
         const int kr = tid >> 4, ns = tid & 15;
         bp = B + (long)(kbeg + kr) * g.ldb + n0 + EPB * ns;
         bstep = (long)GEMM_BK * g.ldb;
-        b_lds = kr * LDB_S + EPB * ns;
+        b_lds = ksw(kr) * LDB_S + EPB * ns;
     }
 
     d2_t ra[EPA / 2], rb[EPB / 2];
     auto gload = [&]() {
 #pragma unroll
-        for (int j = 0; j < EPA / 2; j++) ra[j] = *reinterpret_cast<const d2_t *>(ap + 2 * j);
+        for (int j = 0; j < EPA / 2; j++)
+            ra[j] = *reinterpret_cast<const d2_t *>(ALAY == LAY_KC ? ap + (long)(32 * j) * g.lda : ap + 2 * j);
 #pragma unroll
-        for (int j = 0; j < EPB / 2; j++) rb[j] = *reinterpret_cast<const d2_t *>(bp + 2 * j);
+        for (int j = 0; j < EPB / 2; j++)
+            rb[j] = *reinterpret_cast<const d2_t *>(BLAY == LAY_KC ? bp + (long)(32 * j) * g.ldb : bp + 2 * j);
         ap += astep;
         bp += bstep;
     };
@@ -136,8 +147,8 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
         if (ALAY == LAY_KC) {
 #pragma unroll
             for (int j = 0; j < EPA / 2; j++) {
-                sa[(2 * j) * LDA_S] = ra[j].x;
-                sa[(2 * j + 1) * LDA_S] = ra[j].y;
+                sa[32 * j + a_odd] = ra[j].x;
+                sa[32 * j + LDA_S - a_odd] = ra[j].y;
             }
         } else {
 #pragma unroll
@@ -146,8 +157,8 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
         if (BLAY == LAY_KC) {
 #pragma unroll
             for (int j = 0; j < EPB / 2; j++) {
-                sb[(2 * j) * LDB_S] = rb[j].x;
-                sb[(2 * j + 1) * LDB_S] = rb[j].y;
+                sb[32 * j + b_odd] = rb[j].x;
+                sb[32 * j + LDB_S - b_odd] = rb[j].y;
             }
         } else {
 #pragma unroll
@@ -177,7 +188,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
             for (int j = 0; j < MTN; j++) acc[i][j] = (d4_t){0.0, 0.0, 0.0, 0.0};
     }
 
-    if (g.trace) t_loop0 = wall_clock64();
+    if (g.trace) { t_loop0 = wall_clock64(); c_loop0 = clock64(); }
     if (nk > 0) {
         lstore(0);
         __syncthreads();
@@ -185,29 +196,31 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
         const int fb = (lane >> 4) * LDB_S + WTN * wc + (lane & 15);
         for (int kt = 0; kt < nk; kt++) {
             const int st = kt & 1;
-            if (kt + 1 < nk) gload();
+            if (kt + 1 < nk && TAG < 2) gload();   // TAG 2, 3: timing experiments of jaicov_debug_gemm_trace (wrong results)
             const double *sa = smem + st * STAGE + fa;
             const double *sb = smem + st * STAGE + GEMM_BK * LDA_S + fb;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 double a[MTM], b[MTN];
 #pragma unroll
-                for (int i = 0; i < MTM; i++) a[i] = sa[(4 * ks) * LDA_S + 16 * i];
+                for (int i = 0; i < MTM; i++) a[i] = sa[(4 * ks) * LDA_S + 16 * i + (ALAY == LAY_KC ? 8 * (ks & 1) + 4 * (ks >> 1) : 0)];
 #pragma unroll
-                for (int j = 0; j < MTN; j++) b[j] = sb[(4 * ks) * LDB_S + 16 * j];
+                for (int j = 0; j < MTN; j++) b[j] = sb[(4 * ks) * LDB_S + 16 * j + (BLAY == LAY_KC ? 8 * (ks & 1) + 4 * (ks >> 1) : 0)];
 #pragma unroll
                 for (int i = 0; i < MTM; i++)
 #pragma unroll
                     for (int j = 0; j < MTN; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
             }
+            if (TAG == 3) continue;
             if (kt + 1 < nk) lstore(st ^ 1);
             __syncthreads();
         }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------
-    if (g.trace) t_loop1 = wall_clock64();
+    long long c_loop1 = 0;
+    if (g.trace) { t_loop1 = wall_clock64(); c_loop1 = clock64(); }
 #pragma unroll
     for (int i = 0; i < MTM; i++)
 #pragma unroll
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
         t[0] = t_start; t[1] = t_loop0; t[2] = t_loop1; t[3] = wall_clock64();
         t[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
         t[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+        t[6] = c_loop1 - c_loop0;   // shader-clock cycles of the k loop (against t[2]-t[1] at 100 MHz: the clock the loop ran at)
     }
 }
 
@@ -299,7 +313,9 @@ inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g,
         }
         return hipGetLastError();
     }
-    if (alay == LAY_KC && blay == LAY_KC && tag == 1) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 128, 128, 1>), grid, block, 0, s, g);
+    if (alay == LAY_KC && blay == LAY_KC && tag == 2) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 128, 128, 2>), grid, block, 0, s, g);
+    else if (alay == LAY_KC && blay == LAY_KC && tag == 3) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 128, 128, 3>), grid, block, 0, s, g);
+    else if (alay == LAY_KC && blay == LAY_KC && tag == 1) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 128, 128, 1>), grid, block, 0, s, g);
     else if (alay == LAY_KC && blay == LAY_KC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC>), grid, block, 0, s, g);
     else if (alay == LAY_KC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_XC>), grid, block, 0, s, g);
     else if (alay == LAY_XC && blay == LAY_XC) hipLaunchKernelGGL((gemm_f64_kernel<LAY_XC, LAY_XC>), grid, block, 0, s, g);

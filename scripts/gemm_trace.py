@@ -18,6 +18,8 @@ print(f"tiles={tiles} span={us[:,3].max():.1f} us")
 pro = us[:, 1] - us[:, 0]; loop = us[:, 2] - us[:, 1]; epi = us[:, 3] - us[:, 2]
 for name, v in (("prologue", pro), ("loop", loop), ("epilogue", epi), ("total", us[:, 3] - us[:, 0])):
     print(f"{name:9s} mean={v.mean():7.2f} p10={np.percentile(v,10):7.2f} p50={np.percentile(v,50):7.2f} p90={np.percentile(v,90):7.2f} max={v.max():7.2f}")
+mhz = out[:, 6] / np.maximum(out[:, 2] - out[:, 1], 1) * 100.0
+print(f"shader clock in the k loop: mean {mhz.mean():.0f} MHz  p10 {np.percentile(mhz,10):.0f}  p90 {np.percentile(mhz,90):.0f}")
 hw = out[:, 4]; xcc = out[:, 5] & 0xf
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
 key = xcc * 1000 + se * 100 + sh * 10 + cu
