@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
         a_lds = (2 * seg) * LDA_S + rbase + 8 * ((seg >> 1) & 1) + 4 * (seg >> 2);
     } else {
         const int kr = tid >> 4, ms = tid & 15;
-        ap = A + (long)(kbeg + kr) * g.lda + m0 + EPA * ms;
+        ap = A + (long)(kbeg + kr) * g.lda + m0 + 2 * ms;   // 16 lanes x 16 bytes = 2 lines of one k row per instruction
         astep = (long)GEMM_BK * g.lda;
-        a_lds = ksw(kr) * LDA_S + EPA * ms;
+        a_lds = ksw(kr) * LDA_S + 2 * ms;
     }
     if (BLAY == LAY_KC) {
         bp = B + (n0 + rbase) * g.ldb + kbeg + 2 * seg;
@@ -125,19 +125,19 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
         b_lds = (2 * seg) * LDB_S + rbase + 8 * ((seg >> 1) & 1) + 4 * (seg >> 2);
     } else {
         const int kr = tid >> 4, ns = tid & 15;
-        bp = B + (long)(kbeg + kr) * g.ldb + n0 + EPB * ns;
+        bp = B + (long)(kbeg + kr) * g.ldb + n0 + 2 * ns;
         bstep = (long)GEMM_BK * g.ldb;
-        b_lds = ksw(kr) * LDB_S + EPB * ns;
+        b_lds = ksw(kr) * LDB_S + 2 * ns;
     }
 
     d2_t ra[EPA / 2], rb[EPB / 2];
     auto gload = [&]() {
 #pragma unroll
         for (int j = 0; j < EPA / 2; j++)
-            ra[j] = *reinterpret_cast<const d2_t *>(ALAY == LAY_KC ? ap + (long)(32 * j) * g.lda : ap + 2 * j);
+            ra[j] = *reinterpret_cast<const d2_t *>(ALAY == LAY_KC ? ap + (long)(32 * j) * g.lda : ap + 32 * j);
 #pragma unroll
         for (int j = 0; j < EPB / 2; j++)
-            rb[j] = *reinterpret_cast<const d2_t *>(BLAY == LAY_KC ? bp + (long)(32 * j) * g.ldb : bp + 2 * j);
+            rb[j] = *reinterpret_cast<const d2_t *>(BLAY == LAY_KC ? bp + (long)(32 * j) * g.ldb : bp + 32 * j);
         ap += astep;
         bp += bstep;
     };
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < EPA / 2; j++) *reinterpret_cast<d2_t *>(sa + 2 * j) = ra[j];
+            for (int j = 0; j < EPA / 2; j++) *reinterpret_cast<d2_t *>(sa + 32 * j) = ra[j];
         }
         if (BLAY == LAY_KC) {
 #pragma unroll
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < EPB / 2; j++) *reinterpret_cast<d2_t *>(sb + 2 * j) = rb[j];
+            for (int j = 0; j < EPB / 2; j++) *reinterpret_cast<d2_t *>(sb + 32 * j) = rb[j];
         }
     };
 
