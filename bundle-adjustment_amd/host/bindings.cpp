@@ -179,7 +179,14 @@ PYBIND11_MODULE(_jaicov_host, m) {
         });
 
     py::class_<AiconProject>(m, "AiconProject")
-        .def_property_readonly("camera", [](AiconProject &p) { return p.camera.get(); }, py::return_value_policy::reference_internal)
+        .def_property_readonly("camera", [](AiconProject &p) { return p.camera ? p.camera.get() : (p.cameras.empty() ? nullptr : p.cameras[0].get()); },
+                               py::return_value_policy::reference_internal)
+        .def("cameras", [](AiconProject &p) {
+            std::vector<Camera *> v;
+            if (p.camera) v.push_back(p.camera.get());
+            for (auto &q : p.cameras) v.push_back(q.get());
+            return v;
+        }, py::return_value_policy::reference_internal)
         .def("points", [](AiconProject &p) {
             std::vector<ObjectCoordinate *> v;
             for (auto &q : p.points) v.push_back(q.get());
@@ -193,4 +200,6 @@ PYBIND11_MODULE(_jaicov_host, m) {
         }, py::return_value_policy::reference_internal);
     m.def("read_aicon_flat", [](const std::string &base) { return read_aicon_flat(base).release(); }, py::return_value_policy::take_ownership,
           "AICON flat files <base>.{obc,ior,scale,eor,phc} -> object graph (ExampleFlatFiles.java:76-103)");
+    m.def("read_aicon_report", [](const std::string &path) { return read_aicon_report(path).release(); }, py::return_value_policy::take_ownership,
+          "AICON 3D Studio adjustment report (.htm) -> object graph (AICONReportFileReader.java:117-390)");
 }

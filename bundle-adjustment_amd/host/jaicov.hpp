@@ -41,6 +41,37 @@ enum class ParameterType : int {
     IMAGE_COORDINATE_X = 411, IMAGE_COORDINATE_Y = 412, SCALE_BAR_LENGTH = 511
 };
 
+inline const char *parameterTypeName(ParameterType t) {   // ParameterType.name()
+    switch (t) {
+    case ParameterType::PRINCIPAL_POINT_X: return "PRINCIPAL_POINT_X";
+    case ParameterType::PRINCIPAL_POINT_Y: return "PRINCIPAL_POINT_Y";
+    case ParameterType::PRINCIPAL_DISTANCE: return "PRINCIPAL_DISTANCE";
+    case ParameterType::RADIAL_POLYNOMIAL_A: return "RADIAL_POLYNOMIAL_A";
+    case ParameterType::TANGENTIAL_POLYNOMIAL_B: return "TANGENTIAL_POLYNOMIAL_B";
+    case ParameterType::TANGENTIAL_DISTORTION_Bx: return "TANGENTIAL_DISTORTION_Bx";
+    case ParameterType::TANGENTIAL_DISTORTION_By: return "TANGENTIAL_DISTORTION_By";
+    case ParameterType::AFFINITY_AND_SHEAR_Cx: return "AFFINITY_AND_SHEAR_Cx";
+    case ParameterType::AFFINITY_AND_SHEAR_Cy: return "AFFINITY_AND_SHEAR_Cy";
+    case ParameterType::DISTANCE_POLYNOMIAL_D: return "DISTANCE_POLYNOMIAL_D";
+    case ParameterType::ZERNIKE_POLYNOMIAL_X: return "ZERNIKE_POLYNOMIAL_X";
+    case ParameterType::ZERNIKE_POLYNOMIAL_Y: return "ZERNIKE_POLYNOMIAL_Y";
+    case ParameterType::ZERNIKE_POLYNOMIAL_Z: return "ZERNIKE_POLYNOMIAL_Z";
+    case ParameterType::CAMERA_COORDINATE_X: return "CAMERA_COORDINATE_X";
+    case ParameterType::CAMERA_COORDINATE_Y: return "CAMERA_COORDINATE_Y";
+    case ParameterType::CAMERA_COORDINATE_Z: return "CAMERA_COORDINATE_Z";
+    case ParameterType::CAMERA_OMEGA: return "CAMERA_OMEGA";
+    case ParameterType::CAMERA_PHI: return "CAMERA_PHI";
+    case ParameterType::CAMERA_KAPPA: return "CAMERA_KAPPA";
+    case ParameterType::OBJECT_COORDINATE_X: return "OBJECT_COORDINATE_X";
+    case ParameterType::OBJECT_COORDINATE_Y: return "OBJECT_COORDINATE_Y";
+    case ParameterType::OBJECT_COORDINATE_Z: return "OBJECT_COORDINATE_Z";
+    case ParameterType::IMAGE_COORDINATE_X: return "IMAGE_COORDINATE_X";
+    case ParameterType::IMAGE_COORDINATE_Y: return "IMAGE_COORDINATE_Y";
+    case ParameterType::SCALE_BAR_LENGTH: return "SCALE_BAR_LENGTH";
+    }
+    return "?";
+}
+
 // adjustment/EstimationStateType.java:25-42
 enum class EstimationStateType : int {
     ERROR_FREE_ESTIMATION = 1, BUSY = 0, INTERRUPT = -1, SINGULAR_MATRIX = -2, ROBUST_ESTIMATION_FAILED = -3,
