@@ -6,6 +6,7 @@
 #include <pybind11/stl.h>
 
 #include "aicon_reader.hpp"
+#include "result_writer.hpp"
 #include "jaicov.hpp"
 
 namespace py = pybind11;
@@ -131,6 +132,12 @@ PYBIND11_MODULE(_jaicov_host, m) {
         .def("addPropertyChangeListener", &BundleAdjustment::addPropertyChangeListener)
         .def("setEstimationType", &BundleAdjustment::setEstimationType)
         .def("setInvertNormalEquation", &BundleAdjustment::setInvertNormalEquation)
+        .def("setAdjustmentResultWriter", &BundleAdjustment::setAdjustmentResultWriter, py::keep_alive<1, 2>())
+        .def("hasCofactorMatrix", &BundleAdjustment::hasCofactorMatrix)
+        .def("cofactorSub", [](BundleAdjustment &b, std::vector<int32_t> idx, double scale) {
+            std::vector<double> v = b.cofactorSub(idx, scale);
+            return py::array_t<double>({idx.size(), idx.size()}, v.data());
+        }, py::arg("indices"), py::arg("scale") = 1.0)
         .def("useCentroidedCoordinates", &BundleAdjustment::useCentroidedCoordinates)
         .def("applyAposterioriVarianceOfUnitWeight", &BundleAdjustment::applyAposterioriVarianceOfUnitWeight)
         .def("setLevenbergMarquardtDampingValue", &BundleAdjustment::setLevenbergMarquardtDampingValue)
@@ -177,6 +184,16 @@ PYBIND11_MODULE(_jaicov_host, m) {
             d["sigma2apriori"] = b.getVarianceFactorApriori();
             return d;
         });
+
+    py::class_<AdjustmentResultWritable>(m, "AdjustmentResultWritable")
+        .def("export", &AdjustmentResultWritable::exportResults);
+    py::class_<DefaultResultWriter, AdjustmentResultWritable>(m, "DefaultResultWriter")
+        .def(py::init<std::string>())
+        .def("toString", &DefaultResultWriter::toString);
+    py::class_<MatlabResultWriter, AdjustmentResultWritable>(m, "MatlabResultWriter")
+        .def(py::init<std::string>())
+        .def("toString", &MatlabResultWriter::toString);
+    m.def("java_fixed", &java_fixed, "java.util.Formatter %[+].<prec>f");
 
     py::class_<AiconProject>(m, "AiconProject")
         .def_property_readonly("camera", [](AiconProject &p) { return p.camera ? p.camera.get() : (p.cameras.empty() ? nullptr : p.cameras[0].get()); },

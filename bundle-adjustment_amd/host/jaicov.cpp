@@ -417,17 +417,52 @@ EstimationStateType BundleAdjustment::estimateModel() {
     std::vector<double> v(f.values.size());
     if ((rc = jaicov_neq_get_parameters(engine_, v.data(), v.size())) != JAICOV_OK) return fail(rc);
     pullValues(v);
-    if (wantInverse) {
-        // packed 'U' (column-major upper): the leading k x k block is the leading k(k+1)/2 entries, so the reduced
-        // cofactor matrix lands where the reference's in-place solve(N, n, numRows, true) leaves it (BA:264,274)
-        const size_t k = (size_t)jaicov_neq_cofactor_order(engine_);
-        Qxx_.assign(jaicov_neq_packed_length(engine_), 0.0);
-        if ((rc = jaicov_neq_get_cofactor(engine_, Qxx_.data(), k * (k + 1) / 2)) != JAICOV_OK) return fail(rc);
-    }
+    Qxx_.clear();
+    qxxOnDevice_ = wantInverse;      // fetched by getCofactorMatrix() / gathered by cofactorSub() on demand
     if (centroided_) centroidCoordinates(true);      // BA:357-358
+    if (resultWriter_) {                             // BA:360-368, exportAdjustmentResults BA:1164-1171
+        fire("EXPORT_ADJUSTMENT_RESULTS", 0.0, 0.0);
+        try {
+            resultWriter_->exportResults(*this);
+        } catch (const std::exception &ex) {
+            lastError_ = ex.what();
+            fire("EXPORT_ADJUSTMENT_RESULTS_FAILED", 0.0, 1.0);
+            return EstimationStateType::EXPORT_ADJUSTMENT_RESULTS_FAILED;
+        }
+    }
     status = isConverge ? EstimationStateType::ERROR_FREE_ESTIMATION : EstimationStateType::NO_CONVERGENCE;   // BA:377-384
     fire(isConverge ? "ERROR_FREE_ESTIMATION" : "NO_CONVERGENCE", SQRT_EPS, maxAbsDx_);
     return status;
+}
+
+void BundleAdjustment::fetchCofactor() const {
+    if (!qxxOnDevice_ || !engine_) return;
+    // packed 'U' (column-major upper): the leading k x k block is the leading k(k+1)/2 entries, so the reduced
+    // cofactor matrix lands where the reference's in-place solve(N, n, numRows, true) leaves it (BA:264,274)
+    const size_t k = (size_t)jaicov_neq_cofactor_order(engine_);
+    Qxx_.assign(jaicov_neq_packed_length(engine_), 0.0);
+    const int rc = jaicov_neq_get_cofactor(engine_, Qxx_.data(), k * (k + 1) / 2);
+    if (rc != JAICOV_OK) { Qxx_.clear(); throw std::runtime_error(std::string("jaicov_neq_get_cofactor: ") + jaicov_neq_last_error(engine_)); }
+    qxxOnDevice_ = false;
+}
+
+std::vector<double> BundleAdjustment::cofactorSub(const std::vector<int32_t> &idx, double scale) const {
+    const size_t k = idx.size();
+    std::vector<double> out(k * k);
+    if (k == 0) return out;
+    if (engine_ && (qxxOnDevice_ || !Qxx_.empty())) {
+        const int rc = jaicov_neq_get_dispersion_sub(engine_, scale, idx.data(), (int32_t)k, out.data());
+        if (rc != JAICOV_OK) throw std::runtime_error(std::string("jaicov_neq_get_dispersion_sub: ") + jaicov_neq_last_error(engine_));
+        return out;
+    }
+    if (Qxx_.empty()) throw std::runtime_error("no cofactor matrix (MatrixInversion.NONE or not estimated)");
+    for (size_t r = 0; r < k; r++)
+        for (size_t c = 0; c < k; c++) {
+            int a = idx[r], b = idx[c];
+            if (a > b) std::swap(a, b);
+            out[r * k + c] = scale * Qxx_.at((size_t)a + (size_t)b * (b + 1) / 2);
+        }
+    return out;
 }
 
 }  // namespace jaicov::host

@@ -425,6 +425,14 @@ private:
                ty = DefectType::NOT_SET, tz = DefectType::NOT_SET, mxyz = DefectType::NOT_SET;
 };
 
+class BundleAdjustment;
+class AdjustmentResultWritable {                                   // util/io/writer/AdjustmentResultWritable.java:36
+public:
+    virtual ~AdjustmentResultWritable() = default;
+    virtual void exportResults(BundleAdjustment &bundleAdjustment) = 0;      // `export` is a C++ keyword
+    virtual std::string toString() const = 0;
+};
+
 // BundleAdjustment.java
 class BundleAdjustment {
 public:
@@ -448,6 +456,7 @@ public:
     double getLevenbergMarquardtDampingValue() const { return damping_; }
     void setMaximalNumberOfIterations(int n) { maxIter_ = n; }
     void setDevice(int d) { device_ = d; }
+    void setAdjustmentResultWriter(AdjustmentResultWritable *w) { resultWriter_ = w; }   // BA:1123 (not owned)
     void interrupt() { interrupt_ = true; }                                             // BA:1455
 
     int getNumberOfObservations() const { return numberOfObservations_; }
@@ -466,11 +475,18 @@ public:
     std::vector<ObjectCoordinate *> &getObjectCoordinates() { return objectCoordinates_; }
     std::vector<Camera *> &getCameras() { return cameras_; }
     // packed UPLO='U' cofactor matrix, order u + d (UpperSymmPackMatrix.getData()); empty for MatrixInversion.NONE (BA:1177)
-    const std::vector<double> &getCofactorMatrix() const { return Qxx_; }
+    // The host copy is made on first use: the writers and most callers need a few hundred entries, which cofactorSub
+    // gathers on the device, not the 1.3 GB packed array.
+    const std::vector<double> &getCofactorMatrix() const { fetchCofactor(); return Qxx_; }
     double cofactor(int r, int c) const {
+        fetchCofactor();
         if (r > c) std::swap(r, c);
-        return Qxx_[(size_t)r + (size_t)c * (c + 1) / 2];
+        return Qxx_.at((size_t)r + (size_t)c * (c + 1) / 2);
     }
+    // what the writers test: cofactor != null && numRows >= u + d (MatlabResultWriter.java:72, DefaultResultWriter.java:128)
+    bool hasCofactorMatrix() const { return inversion_ != MatrixInversion::NONE && (qxxOnDevice_ || !Qxx_.empty()); }
+    // scale * Qxx[idx, idx], row-major k x k, gathered on the device (jaicov_neq_get_dispersion_sub)
+    std::vector<double> cofactorSub(const std::vector<int32_t> &idx, double scale = 1.0) const;
     const std::string &lastError() const { return lastError_; }
 
     // ---- index contract -----------------------------------------------------------------------------------
@@ -521,7 +537,10 @@ private:
     bool interrupt_ = false, applyAposteriori_ = true, centroided_ = true, prepared_ = false;
     double damping_ = 0.0, omega_ = 0.0, sigma2apriori_ = 1.0, maxAbsDx_ = 0.0;
     double centroid_[3] = {0, 0, 0};
-    std::vector<double> Qxx_;
+    mutable std::vector<double> Qxx_;
+    mutable bool qxxOnDevice_ = false;    // an inverse is on the device and Qxx_ has not been fetched yet
+    void fetchCofactor() const;
+    AdjustmentResultWritable *resultWriter_ = nullptr;
     std::string lastError_;
     jaicov_engine *engine_ = nullptr;
 };

@@ -409,3 +409,117 @@ def test_native_example_report_program(example_report):
     sig = np.array([[float(r[4]), float(r[5]), float(r[6])] for r in rows])
     assert np.all(sig > 0) and np.all(sig < 0.1)          # mm; the protocol lists 0.008 .. 0.02 (example.htm:1608ff)
     assert "PRINCIPAL_DISTANCE" in out.stdout and "RADIAL_POLYNOMIAL_A(3)" in out.stdout and "fixed" in out.stdout
+
+
+def test_java_fixed_follows_the_java_formatter(H):
+    """The text writers print with java.util.Formatter's %f (DefaultResultWriter.java:70,145): the shortest round-trip digits
+    (Double.toString), rounded HALF_UP, zero padded -- where C's printf would go on with the binary expansion (0.1 ->
+    0.1000000000000000055...) and round half-even on it (0.125 -> 0.12)."""
+    cases = [((0.1, 20, False), "0.10000000000000000000"), ((1234.5678, 15, True), "+1234.567800000000000"),
+             ((-1.23456789012345678e-7, 15, False), "-0.000000123456789"), ((0.125, 2, False), "0.13"), ((2.5, 0, False), "3"),
+             ((0.99999, 2, True), "+1.00"), ((1e22, 2, False), "10000000000000000000000.00"), ((5e-324, 3, False), "0.000"),
+             ((0.0, 3, True), "+0.000"), ((123456789.987654321, 15, False), "123456789.987654330000000"),
+             ((-99.9999999999999999, 3, True), "-100.000"), ((float("nan"), 3, True), "NaN"), ((float("-inf"), 3, True), "-Infinity")]
+    for args, want in cases:
+        assert H.java_fixed(*args) == want, (args, H.java_fixed(*args))
+
+
+def test_result_writers_without_cofactor(H, example_base, tmp_path):
+    """MatlabResultWriter.java:60-222 / DefaultResultWriter.java:62-117 before any inversion (cofactor == null): variables,
+    classes and struct fields of the .mat (read back with scipy), the .info listing, no `cov` fields, no dispersion, no .cxx."""
+    import scipy.io
+    pr, ba = example_adjustment(H, example_base)
+    ba.prepareUnknownParameters()
+    base = str(tmp_path / "result")
+    H.MatlabResultWriter(base).export(ba)
+    H.DefaultResultWriter(base).export(ba)
+    m = scipy.io.loadmat(base + ".mat")
+    assert m["variance_of_unit_weight_prio"].dtype == np.float64 and m["degree_of_freedom"].dtype == np.int32
+    assert int(m["number_of_observations"][0, 0]) == 19945 and int(m["number_of_unknowns"][0, 0]) == 1147
+    assert int(m["degree_of_freedom"][0, 0]) == 18804 and "dispersion" not in m
+    c = m["coordinates"]
+    assert c.shape == (1, 150) and c.dtype.names == ("name", "X", "Y", "Z", "covx", "covy", "covz")
+    pts = ba.getObjectCoordinates()
+    k = 1
+    for i, p in enumerate(pts):
+        e = c[0, i]
+        assert e["name"][0] == p.getName() and e["X"][0, 0] == p.getX().getValue() and e["Z"][0, 0] == p.getZ().getValue()
+        assert e["covx"].dtype == np.int32 and [int(e[f][0, 0]) for f in ("covx", "covy", "covz")] == [k, k + 1, k + 2]
+        k += 3
+    io = m["interior_orientations"]
+    assert io.dtype.names == ("cam_id", "name", "value") and io.shape == (1, 3)
+    assert [str(io[0, i]["name"][0]) for i in range(3)] == ["principal_point_x", "principal_point_y", "principal_distance"]
+    assert io[0, 0]["cam_id"].dtype == np.int64 and io[0, 2]["value"][0, 0] == 28.78507
+    di = m["distortion_parameters"]
+    assert di.dtype.names == ("cam_id", "name", "value", "order") and di.shape == (1, 7)
+    names = [(str(di[0, i]["name"][0]), int(di[0, i]["order"][0, 0])) for i in range(7)]
+    assert names == [("affinity_and_shear_cx", -1), ("affinity_and_shear_cy", -1), ("tangential_distortion_bx", -1),
+                     ("tangential_distortion_by", -1), ("radial_polynomial_a", 1), ("radial_polynomial_a", 2), ("radial_polynomial_a", 3)]
+    lines = open(base + ".info").read().split("\n")
+    assert len(lines) == 3 * 150 + 1 and lines[-1] == ""
+    p0 = pts[0]
+    assert lines[0] == "%25s\t%5s\t%35s\t%10d" % (p0.getName(), "X", H.java_fixed(p0.getX().getValue(), 15, False), 0)
+    assert lines[4] == "%25s\t%5s\t%35s\t%10d" % (pts[1].getName(), "Y", H.java_fixed(pts[1].getY().getValue(), 15, False), 4)
+    assert not os.path.exists(base + ".cxx")
+    with pytest.raises(Exception):
+        H.MatlabResultWriter("").export(ba)                      # "Error, export path cannot be null!"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["FULL", "REDUCED"])
+def test_result_writers_export_the_device_gathered_dispersion(H, example_base, tmp_path, mode):
+    """estimateModel() with a result writer set (BA:360-368): the .mat `dispersion` is the cofactor block of
+    points + interior orientation + distortion (MatlabResultWriter.java:210-221, unscaled), the .cxx block is
+    sigma2apost * Qxx of the points (DefaultResultWriter.java:139-147) -- both gathered on the device, compared with the
+    host copy of the packed matrix."""
+    import scipy.io
+    base = str(tmp_path / "adjustment_results")
+    results = {}
+    for W in (H.MatlabResultWriter, H.DefaultResultWriter):
+        pr, ba = example_adjustment(H, example_base)
+        ba.setInvertNormalEquation(getattr(H.MatrixInversion, mode))
+        events = []
+        ba.addPropertyChangeListener(lambda n, a, b: events.append(n))
+        w = W(base)
+        ba.setAdjustmentResultWriter(w)
+        assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+        assert "EXPORT_ADJUSTMENT_RESULTS" in events and ba.hasCofactorMatrix()
+        results[W] = (pr, ba)
+    pr, ba = results[H.MatlabResultWriter]
+    U = ba.getNumberOfUnknownParameters() + ba.getNumberOfDatumConditions()
+    Q = packed_to_full(np.asarray(ba.getCofactorMatrix()), U)
+    m = scipy.io.loadmat(base + ".mat")
+    idx = []
+    for p in ba.getObjectCoordinates():
+        idx += [p.getX().getColumn(), p.getY().getColumn(), p.getZ().getColumn()]
+    cam = pr.camera
+    io = cam.getInteriorOrientation()
+    par = [io.getPrinciplePointX(), io.getPrinciplePointY(), io.getPrincipleDistance()]
+    for t in (H.DistortionModelType.AFFINITY_AND_SHEAR, H.DistortionModelType.TANGENTIAL_DISTORTION, H.DistortionModelType.RADIAL_DISTORTION):
+        par += list(cam.getDistortionModel(t).parameters())
+    cov = [int(m["interior_orientations"][0, i]["cov"][0, 0]) for i in range(3)] + \
+          [int(m["distortion_parameters"][0, i]["cov"][0, 0]) for i in range(7)]
+    nxt = len(idx) + 1
+    for u, c in zip(par, cov):
+        if 0 <= u.getColumn() < U:
+            assert c == nxt
+            idx.append(u.getColumn()); nxt += 1
+        else:
+            assert c == -1                                          # A3, Cx, Cy are fixed
+    D = m["dispersion"]
+    assert D.shape == (len(idx), len(idx)) and len(idx) == 3 * 150 + 7
+    np.testing.assert_array_equal(D, Q[np.ix_(idx, idx)])
+    assert float(m["variance_of_unit_weight_post"][0, 0]) == ba.getVarianceFactorAposteriori()
+    # text writer: 450 x 450 block of the points, scaled
+    pr2, ba2 = results[H.DefaultResultWriter]
+    Q2 = packed_to_full(np.asarray(ba2.getCofactorMatrix()), U)
+    pidx = idx[:450]
+    rows = open(base + ".cxx").read().split("\n")
+    assert len(rows) == 451 and rows[-1] == "" and all(len(r) == 450 * 37 for r in rows[:-1])
+    T = np.array([[float(r[37 * j:37 * j + 35]) for j in range(450)] for r in rows[:-1]])
+    np.testing.assert_allclose(T, ba2.getVarianceFactorAposteriori() * Q2[np.ix_(pidx, pidx)], rtol=0, atol=6e-16)
+    assert rows[0][:35].lstrip()[0] in "+-"
+    # a writer that cannot write: BA:362-367
+    pr3, ba3 = example_adjustment(H, example_base)
+    ba3.setAdjustmentResultWriter(H.MatlabResultWriter(str(tmp_path / "no_such_dir" / "x")))
+    assert ba3.estimateModel() == H.EstimationStateType.EXPORT_ADJUSTMENT_RESULTS_FAILED
