@@ -35,6 +35,8 @@ PYBIND11_MODULE(_jaicov_host, m) {
         .value("ERROR_FREE_ESTIMATION", EstimationStateType::ERROR_FREE_ESTIMATION).value("BUSY", EstimationStateType::BUSY)
         .value("INTERRUPT", EstimationStateType::INTERRUPT).value("SINGULAR_MATRIX", EstimationStateType::SINGULAR_MATRIX)
         .value("NO_CONVERGENCE", EstimationStateType::NO_CONVERGENCE).value("NOT_INITIALISED", EstimationStateType::NOT_INITIALISED)
+        .value("ROBUST_ESTIMATION_FAILED", EstimationStateType::ROBUST_ESTIMATION_FAILED)
+        .value("EXPORT_ADJUSTMENT_RESULTS_FAILED", EstimationStateType::EXPORT_ADJUSTMENT_RESULTS_FAILED)
         .value("OUT_OF_MEMORY", EstimationStateType::OUT_OF_MEMORY);
     py::enum_<EstimationType>(m, "EstimationType").value("L2NORM", EstimationType::L2NORM).value("SIMULATION", EstimationType::SIMULATION);
     py::enum_<MatrixInversion>(m, "MatrixInversion")
