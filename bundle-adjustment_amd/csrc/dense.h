@@ -52,7 +52,7 @@ struct DenseSolver {
     double *rhs_row(int q) const { return L + (long)(nfact + q) * ld; }   // row q of the right-hand sides / of Z = Y L^-T
     void release();
     hipError_t panel(hipStream_t st, int K0, int K1);
-    hipError_t timed_gemm(hipStream_t st, const GemmArgs &u, double flops);
+    hipError_t timed_gemm(hipStream_t st, const GemmArgs &u, double flops, int small = 0);
     hipError_t potrf();                                     // L <- chol(L); info via fetch_info()
     hipError_t backsolve_aug(double *X, long xs, int nrhs);  // L' X = Z, Z = the rhs rows after potrf(); X rows have stride xs
     hipError_t trtri();                                     // W <- L^-1

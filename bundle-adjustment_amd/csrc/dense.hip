@@ -472,7 +472,10 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
     for (int k = K0; k < K1; k++) {
         double *Akk = L + (long)(k * 128) * ld + k * 128;
         const int rows_k = n - k * 128;
-        const bool split = dstream != nullptr && st == pstream && rows_k > tail_rows;
+        // ... except for the first block of a panel: it becomes ready at the moment the trailing update is launched, and a
+        // workgroup that wants a whole CU's LDS then waits for the update's first tiles to retire (130 us instead of 49)
+        static const bool first_split = !(getenv("JAICOV_TAIL_FIRST_SPLIT") && atoi(getenv("JAICOV_TAIL_FIRST_SPLIT")) == 0);
+        const bool split = dstream != nullptr && st == pstream && (rows_k > tail_rows || (first_split && k == K0));
         // While the trailing update still hides the panel (many rows left) the panel GEMMs take the 128-tile: it costs
         // the update fewer CU slots per flop than the 64-tile latency variant, which is for the critical-path regime.
         static const int bulk_rows = getenv("JAICOV_BULK_ROWS") ? atoi(getenv("JAICOV_BULK_ROWS")) : 9216;
@@ -511,7 +514,7 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
     return hipGetLastError();
 }
 
-hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flops) {
+hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flops, int small) {
     if (profile) {
         if (prof_used + 2 > prof_ev.size()) {
             hipEvent_t a, b;
@@ -520,7 +523,7 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
         }
         HIPCHK(hipEventRecord(prof_ev[prof_used], st));
     }
-    HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, u, 1, 0, 1));   // own kernel symbol: gemm_f64_kernel<0, 0, 128, 128, 1>
+    HIPCHK(gemm_f64(st, LAY_KC, LAY_KC, u, 1, small, 1));   // own kernel symbol: gemm_f64_kernel<0, 0, 128, 128, 1> (64, 64 in the tail)
     if (profile) {
         HIPCHK(hipEventRecord(prof_ev[prof_used + 1], st));
         prof_flops.push_back(flops);
@@ -593,7 +596,11 @@ hipError_t DenseSolver::potrf() {
                     u.n_map = it->second.second;
                 }
             }
-            HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
+            // tail: the panel chain is the critical path and its workgroups queue behind the update's; 64-tiles retire 4x
+            // as often (the update itself is not on the critical path there)
+            static const int upd64_rows = getenv("JAICOV_UPDATE64_ROWS") ? atoi(getenv("JAICOV_UPDATE64_ROWS")) : 0;
+            const int small_u = (la && rows <= upd64_rows) ? 1 : 0;
+            HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw, small_u));
         }
         K0 = K1;
         K1 = K2;

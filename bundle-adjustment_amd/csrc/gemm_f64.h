@@ -289,6 +289,17 @@ inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g,
     const int tm = g.M / 128, tn = g.N / 128;
     const int tiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
     dim3 grid(g.tile_map ? g.n_map : tiles, batch), block(256);
+    if (g.lower_only && small_tiles == 1 && g.kmode == KMODE_FULL && alay == LAY_KC && blay == LAY_KC && g.M == g.N) {
+        // lower-triangular grid in 64-tiles: 4x the workgroups, a quarter of the time each.  For the trailing update of
+        // the factorisation's tail, where the panel chain on the other stream waits for its workgroups to retire.
+        GemmArgs h = g;
+        h.tile_map = nullptr; h.n_map = 0;
+        const int t64 = g.M / 64;
+        grid.x = t64 * (t64 + 1) / 2;
+        if (tag == 1) hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 64, 1>), grid, block, 0, s, h);
+        else hipLaunchKernelGGL((gemm_f64_kernel<LAY_KC, LAY_KC, 64, 64>), grid, block, 0, s, h);
+        return hipGetLastError();
+    }
     const bool can_small = !g.lower_only && g.kmode == KMODE_FULL && alay == LAY_KC && blay == LAY_KC;
     if (can_small && (small_tiles > 0 || (small_tiles < 0 && tiles * batch < GEMM_SMALL_TILE_LIMIT))) {
         // even the 64-tile leaves most SIMDs idle when only a few block rows remain; a wave then spends its k-step in
