@@ -523,3 +523,173 @@ def test_result_writers_export_the_device_gathered_dispersion(H, example_base, t
     pr3, ba3 = example_adjustment(H, example_base)
     ba3.setAdjustmentResultWriter(H.MatlabResultWriter(str(tmp_path / "no_such_dir" / "x")))
     assert ba3.estimateModel() == H.EstimationStateType.EXPORT_ADJUSTMENT_RESULTS_FAILED
+
+
+def _report_interior_precision(path):
+    """Standard deviations and correlation matrix of the estimated interior-orientation parameters as printed by AICON 3D
+    Studio in the bundled report (example.htm:77-98): third-party results for the same observations."""
+    lines = open(path, encoding="latin-1").read().split("\n")
+    start = next(i for i, l in enumerate(lines) if 'name="interior_orientations"' in l)
+    sig, order, corr = {}, [], {}
+    i = start + 1
+    while not lines[i].startswith("Korrelation"):
+        t = lines[i].replace(":", " ").split()
+        if len(t) == 3 and "/" not in t[0] and t[2] != "fest":
+            sig[t[0]] = float(t[2])
+        i += 1
+    i += 1
+    while True:
+        t = lines[i].split()
+        i += 1
+        if not t:
+            if order:
+                break
+            continue
+        if t[0] in sig and len(t) == len(order) + 2:
+            order.append(t[0])
+            for name, v in zip(order, t[1:]):
+                corr[(t[0], name)] = corr[(name, t[0])] = float(v)
+        else:
+            break
+    return sig, order, corr
+
+
+def _check_interior_precision(H, cam, dispersion_of, report):
+    """dispersion_of(list of columns) -> sigma2apost * Qxx block.  Interior orientation and distortion are invariant to the
+    choice of the (minimal) datum, so AICON's values must come out although its datum differs (ExampleReport.java:71-82).
+    The report lists Ck, the engine estimates c = -Ck: correlations with Ck change sign."""
+    sig, order, corr = _report_interior_precision(report)
+    assert order == ["Ck", "Xh", "Yh", "A1", "A2", "B1", "B2"]
+    io = cam.getInteriorOrientation()
+    rad = cam.getDistortionModel(H.DistortionModelType.RADIAL_DISTORTION)
+    tan = cam.getDistortionModel(H.DistortionModelType.TANGENTIAL_DISTORTION)
+    par = {"Ck": io.getPrincipleDistance(), "Xh": io.getPrinciplePointX(), "Yh": io.getPrinciplePointY(), "A1": rad.get(1),
+           "A2": rad.get(2), "B1": tan.getBx(), "B2": tan.getBy()}
+    C = dispersion_of([par[n].getColumn() for n in order])
+    s = np.sqrt(np.diag(C))
+    for k, n in enumerate(order):
+        assert abs(s[k] / sig[n] - 1.0) < 2e-5, (n, s[k], sig[n])        # the report prints 7 digits
+    R = C / np.outer(s, s)
+    for a, na in enumerate(order):
+        for b, nb in enumerate(order):
+            flip = -1.0 if (na == "Ck") != (nb == "Ck") else 1.0
+            assert abs(R[a, b] - flip * corr[(na, nb)]) < 6e-4, (na, nb, R[a, b], corr[(na, nb)])   # printed with 3 decimals
+
+
+def test_oracle_reproduces_the_reports_interior_orientation_precision(H, example_report, oracle_mod):
+    """Pins the oracle's covariance path (datum border, Bunch-Kaufman solve + inverse, a-posteriori variance factor;
+    BA:493-635, MX:338-366, BA:1090-1093) on third-party numbers held by the reference's own example: the standard
+    deviations (6 digits) and the correlation matrix (3 decimals) of c, x0, y0, A1, A2, B1, B2 in example.htm:77-98."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr = H.read_aicon_report(example_report)
+    cam = pr.cameras()[0]
+    for p in pr.points():
+        if len(p.getName()) > 3:
+            p.setDatum(False)
+    ba = H.BundleAdjustment()
+    ba.add(cam)
+    for sb in pr.scaleBars():
+        ba.add(sb)
+    ba.useCentroidedCoordinates(False)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba).validate()
+    v, Q, res = oracle_mod.Oracle(fp).estimate()
+    assert res.state == 1
+    s2 = res.omega / fp.degree_of_freedom
+    Qf = packed_to_full(np.asarray(Q), fp.n_unknowns)
+    _check_interior_precision(H, cam, lambda cols: s2 * Qf[np.ix_(cols, cols)], example_report)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["REDUCED", "FULL"])
+def test_engine_reproduces_the_reports_interior_orientation_precision(H, example_report, mode):
+    """The same third-party numbers from the engine: report reader -> estimateModel() on the MI355X -> dispersion block
+    gathered on the device (the writers' path)."""
+    pr = H.read_aicon_report(example_report)
+    cam = pr.cameras()[0]
+    for p in pr.points():
+        if len(p.getName()) > 3:
+            p.setDatum(False)
+    ba = H.BundleAdjustment()
+    ba.add(cam)
+    for sb in pr.scaleBars():
+        ba.add(sb)
+    ba.setInvertNormalEquation(getattr(H.MatrixInversion, mode))
+    assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+    assert abs(np.sqrt(ba.getVarianceFactorAposteriori()) - 0.000405) < 1.5e-6
+    _check_interior_precision(H, cam, lambda cols: ba.cofactorSub(cols, ba.getVarianceFactorAposteriori()), example_report)
+
+
+def _report_point_and_station_precision(path):
+    """sx, sy, sz of the object points (example.htm:1608ff) and of the projection centres (example.htm:108ff), 4 decimals."""
+    import re
+    lines = open(path, encoding="latin-1").read().split("\n")
+    a = next(i for i, l in enumerate(lines) if 'name="exterior_orientations"' in l)
+    b = next(i for i, l in enumerate(lines) if 'name="object_points"' in l)
+    c = next(i for i, l in enumerate(lines) if 'name="image_coordinates"' in l)
+    eo, pts = {}, {}
+    for l in lines[a:b]:
+        t = l.split()
+        if len(t) == 9 and t[0].isdigit() and t[1].isdigit():
+            eo[int(t[0])] = [float(x) for x in t[5:8]]
+    for l in lines[b:c]:
+        t = l.split()
+        if len(t) == 9 and re.match(r"^\w+$", t[0]):
+            try:
+                pts[t[0]] = [float(x) for x in t[4:7]]
+            except ValueError:
+                pass
+    return pts, eo
+
+
+def _check_point_and_station_precision(H, ba, cam, sigma_of, report):
+    pts, eo = _report_point_and_station_precision(report)
+    assert len(pts) == 150 and len(eo) == 115
+    PT = H.ParameterType
+    worst = 0.0
+    for p in ba.getObjectCoordinates():
+        s = sigma_of([p.getX().getColumn(), p.getY().getColumn(), p.getZ().getColumn()])
+        worst = max(worst, np.abs(s - np.array(pts[p.getName()])).max())
+    for im in cam.images():
+        e = im.getExteriorOrientation()
+        s = sigma_of([e.get(t).getColumn() for t in (PT.CAMERA_COORDINATE_X, PT.CAMERA_COORDINATE_Y, PT.CAMERA_COORDINATE_Z)])
+        worst = max(worst, np.abs(s - np.array(eo[im.getId()])).max())
+    assert worst < 5.1e-5, worst          # the report prints 4 decimals (mm)
+
+
+def _report_adjustment_in_aicons_datum(H, example_report):
+    """The report reader marks every point as datum point (AICONReportFileReader.java:262): the free-network datum over
+    all object points, which is the one AICON's own adjustment used (example.htm:55-73) -- no ExampleReport re-selection."""
+    pr = H.read_aicon_report(example_report)
+    cam = pr.cameras()[0]
+    ba = H.BundleAdjustment()
+    ba.add(cam)
+    for sb in pr.scaleBars():
+        ba.add(sb)
+    return pr, cam, ba
+
+
+def test_oracle_reproduces_the_reports_point_and_station_precision(H, example_report, oracle_mod):
+    """Second third-party pin of the oracle: in AICON's own datum (inner constraints over all 150 points, b = 6) the
+    a-posteriori standard deviations of all object coordinates (450 values) and projection centres (345 values) agree with
+    the report to its printed precision -- datum rows (BA:493-635), solve + inverse (MX:338-366), sigma0 (BA:1090-1093)."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr, cam, ba = _report_adjustment_in_aicons_datum(H, example_report)
+    ba.useCentroidedCoordinates(False)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba).validate()
+    assert fp.rank_defect == 6
+    v, Q, res = oracle_mod.Oracle(fp).estimate()
+    assert res.state == 1
+    s2 = res.omega / fp.degree_of_freedom
+    d = np.diag(packed_to_full(np.asarray(Q), fp.n_unknowns))
+    _check_point_and_station_precision(H, ba, cam, lambda cols: np.sqrt(s2 * d[cols]), example_report)
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_reports_point_and_station_precision(H, example_report):
+    pr, cam, ba = _report_adjustment_in_aicons_datum(H, example_report)
+    ba.setInvertNormalEquation(H.MatrixInversion.FULL)
+    assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+    s2 = ba.getVarianceFactorAposteriori()
+    _check_point_and_station_precision(H, ba, cam, lambda cols: np.sqrt(np.diag(ba.cofactorSub(cols, s2))), example_report)
