@@ -12,7 +12,8 @@
  *       and its near-fixed-point behaviour; from the same third-party report (tests/golden/example/example.htm.gz) the
  *       a-posteriori S0 = 0.000405, the standard deviations (6 digits) and correlations (3 decimals) of the interior
  *       orientation (example.htm:77-98), and in AICON's datum the standard deviations of all object points and projection
- *       centres (4 decimals, 795 values) -- tests/test_host.py::test_oracle_reproduces_the_reports_*,
+ *       centres (4 decimals, 795 values), and the 19 944 image-coordinate residuals (6 decimals) --
+ *       tests/test_host.py::test_oracle_reproduces_the_reports_*,
  *   (3) LAPACK dsytrf/dsysv/dpotrf as shipped with scipy for the packed solver restatements.
  * The third-party arithmetic the reference delegates to -- com.googlecode.matrix-toolkits-java:mtj:1.0.4 and
  * com.github.fommil.netlib:core:1.1.2 (F2jLAPACK dspsv/dsptrf/dsptrs/dsptri/dpptrf/dpptri) -- exists in

@@ -693,3 +693,63 @@ def test_engine_reproduces_the_reports_point_and_station_precision(H, example_re
     assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
     s2 = ba.getVarianceFactorAposteriori()
     _check_point_and_station_precision(H, ba, cam, lambda cols: np.sqrt(np.diag(ba.cofactorSub(cols, s2))), example_report)
+
+
+def _report_residuals(path):
+    """AICON's corrections vx, vy of every image coordinate that took part in its adjustment (example.htm:1766ff, 6 decimals)."""
+    lines = open(path, encoding="latin-1").read().split("\n")
+    a = next(i for i, l in enumerate(lines) if 'name="image_coordinates"' in l)
+    b = next(i for i, l in enumerate(lines) if 'name="distances"' in l)
+    rep = {}
+    for l in lines[a:b]:
+        t = l.split()
+        if len(t) == 12 and not l.rstrip().endswith("***"):
+            try:
+                rep[(t[0], int(t[1]))] = (float(t[4]), float(t[5]))
+            except ValueError:
+                pass
+    return rep
+
+
+def _check_residuals(cam, w_of, report):
+    """w = observed - computed at the adjusted parameters must be minus AICON's corrections (computed - observed): the
+    residuals do not depend on the datum, so all 19 944 of them pin the functional model -- collinearity, radial (A1..A3
+    with R0), tangential, affinity -- on third-party values."""
+    rep = _report_residuals(report)
+    assert len(rep) == 9972
+    k, worst = 0, 0.0
+    for im in cam.images():
+        for ic in im.coordinates():
+            vx, vy = rep[(ic.getObjectCoordinate().getName(), im.getId())]
+            w = w_of(k)
+            worst = max(worst, abs(w[0] + vx), abs(w[1] + vy))
+            k += 1
+    assert k == 9972 and worst < 1.5e-6, worst        # mm; the report prints 6 decimals
+
+
+def test_oracle_reproduces_the_reports_residuals(H, example_report, oracle_mod):
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr, cam, ba = _report_adjustment_in_aicons_datum(H, example_report)
+    ba.useCentroidedCoordinates(False)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba).validate()
+    O = oracle_mod.Oracle(fp)
+    v, Q, res = O.estimate(invert=False)
+    assert res.state == 1
+    _check_residuals(cam, lambda k: O.rows(v, k)[0], example_report)
+
+
+@pytest.mark.gpu
+def test_engine_reproduces_the_reports_residuals(H, example_report):
+    from bundle_adjustment_amd import engine
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr, cam, ba = _report_adjustment_in_aicons_datum(H, example_report)
+    ba.useCentroidedCoordinates(False)
+    ba.setInvertNormalEquation(H.MatrixInversion.NONE)
+    assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+    ba.flatten()                                   # the adjusted values, flattened again
+    fp = flat_problem(ba).validate()
+    with engine.Engine(fp) as eng:
+        eng.set_parameters(fp.values)
+        w, A = eng.get_rows(0, fp.n_image_points)
+    _check_residuals(cam, lambda k: w[k], example_report)
