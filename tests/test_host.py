@@ -749,7 +749,10 @@ def test_engine_reproduces_the_reports_residuals(H, example_report):
     assert ba.estimateModel() == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
     ba.flatten()                                   # the adjusted values, flattened again
     fp = flat_problem(ba).validate()
-    with engine.Engine(fp) as eng:
+    eng = engine.Engine(fp)
+    try:
         eng.set_parameters(fp.values)
         w, A = eng.get_rows(0, fp.n_image_points)
+    finally:
+        eng.close()
     _check_residuals(cam, lambda k: w[k], example_report)
