@@ -126,3 +126,14 @@ JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_
     (*e)->ReleasePrimitiveArrayCritical(e, q, p, 0);
     return rc;
 }
+JNIEXPORT jint JNICALL Java_org_applied_1geodesy_adjustment_bundle_nativeengine_NativeNormalEquationEngine_getDispersionSub(
+    JNIEnv *e, jclass k, jlong h, jdouble scale, jintArray idx, jdoubleArray out) {
+    jsize n = (*e)->GetArrayLength(e, idx);
+    if ((*e)->GetArrayLength(e, out) < n * n) return JAICOV_ERR_BAD_ARGUMENT;
+    jint *ip = (*e)->GetIntArrayElements(e, idx, NULL);          /* jint is int32_t */
+    double *p = (*e)->GetPrimitiveArrayCritical(e, out, NULL);
+    int rc = jaicov_neq_get_dispersion_sub(ENG(h), scale, (const int32_t *)ip, (int32_t)n, p);
+    (*e)->ReleasePrimitiveArrayCritical(e, out, p, 0);
+    (*e)->ReleaseIntArrayElements(e, idx, ip, JNI_ABORT);
+    return rc;
+}

@@ -45,6 +45,16 @@ public final class NativeNormalEquationEngine implements AutoCloseable {
 	public void getParameters(double[] slots) { check(getParameters(handle, slots)); }
 	/** UpperSymmPackMatrix.getData() order (UPLO='U'), length U(U+1)/2: new UpperSymmPackMatrix(U) then copy */
 	public void getCofactor(double[] packed) { check(getCofactor(handle, packed)); }
+	/**
+	 * scale * Qxx[indices, indices] as a dense row-major k x k block, gathered (and scaled) on the device: what
+	 * DefaultResultWriter.java:139-147 (scale = sigma2apost) and MatlabResultWriter.java:210-221 (scale = 1) read
+	 * element by element from the packed matrix.  The writers replace their double loop by one call.
+	 */
+	public double[] getDispersionSub(double scale, int[] indices) {
+		double[] out = new double[indices.length * indices.length];
+		check(getDispersionSub(handle, scale, indices, out));
+		return out;
+	}
 
 	@Override public void close() { if (handle != 0) { destroy(handle); handle = 0; } }
 
@@ -68,4 +78,5 @@ public final class NativeNormalEquationEngine implements AutoCloseable {
 	private static native int omega(long h, double sigma2, double[] dx, double[] out);
 	private static native int update(long h, double[] dx, double[] maxAbs);
 	private static native int getCofactor(long h, double[] packed);
+	private static native int getDispersionSub(long h, double scale, int[] indices, double[] out);
 }
