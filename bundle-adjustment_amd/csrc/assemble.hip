@@ -349,7 +349,7 @@ __device__ __forceinline__ void pp_accumulate(const PPData &d, const double (&ap
     }
 }
 
-__global__ __launch_bounds__(PP_NT) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
+__global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             double sigma2, double *__restrict__ N) {
     __shared__ double strip[3 * PP_CW];
     constexpr int NW = PP_NT / 64;
