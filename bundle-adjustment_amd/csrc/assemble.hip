@@ -224,7 +224,10 @@ __global__ __launch_bounds__(256) void blk_cc_kernel(DevProblem p, const int32_t
         const double *ra = rowsA + (long)(2 * shared_local(a)) * S + ipb;
         const double *tb = T + (long)2 * ipb * KC_LD + bb;
         double s = 0.0;
-        for (int o = 0; o < m / 2; o++)
+        // the rows of the block are dealt to gridDim.y workgroups (one workgroup per image left 500 serial iterations on
+        // a quarter-filled chip); the partial sums meet in the atomics below
+        const int o0 = (int)((long)(m / 2) * blockIdx.y / gridDim.y), o1 = (int)((long)(m / 2) * (blockIdx.y + 1) / gridDim.y);
+        for (int o = o0; o < o1; o++)
             s += ra[o] * tb[(long)(2 * o) * KC_LD] + ra[S + o] * tb[(long)(2 * o + 1) * KC_LD];
         s *= sigma2;
         if (bb == kc) unsafeAtomicAdd(n + ga, s);
@@ -592,7 +595,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         q.blk_w = sb.Pp;
         s2 = 1.0;
     }
-    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
+    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, 8), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
     hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
                        ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
