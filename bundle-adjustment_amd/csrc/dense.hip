@@ -560,6 +560,67 @@ hipError_t DenseSolver::potrf() {
     HIPCHK(panel(sp, 0, K1));
     hipEvent_t e_panel = next_event();
     if (la) HIPCHK(hipEventRecord(e_panel, sp));
+    // Alternative schedule with the next panel's columns updated early (JAICOV_SPLIT_UPDATE=1; measured equal to the
+    // default below within +-0.2 ms at config 4, so the simpler one stays the default).  With L_k the panel
+    // factored last, [K1,K2) the next panel and [K2,K3) the one after:
+    //   update stream:  (b1)_k  columns [K2,K3) -= L_k ...   then   (b2)_k  lower square from K3 on -= L_k ...
+    //   panel stream :  panel [K1,K2)  ->  (a)_{k+1}  columns [K2,K3) -= L_{k+1} ...  (after (b1)_k)  ->  panel [K2,K3)  -> ...
+    // so the panel stream never waits for the bulk of an update, and the narrow GEMM (a), which cannot fill the chip once
+    // fewer than ~7000 rows are left, runs beside (b2) instead of alone between two updates.  Updates of one tile by
+    // different panels commute but must not overlap in time: (b1)_k and (a)_{k+1} are ordered by an event, everything
+    // else by stream order.
+    static const bool split_update = getenv("JAICOV_SPLIT_UPDATE") && atoi(getenv("JAICOV_SPLIT_UPDATE")) != 0;
+    if (la && split_update) {
+        auto rect = [&](hipStream_t st, int Ka, int Kb, int C0, int C1) -> hipError_t {
+            // C[rows >= C0, cols [C0,C1)] -= L[rows >= C0, cols [Ka,Kb)] * L[rows [C0,C1), cols [Ka,Kb)]'
+            GemmArgs a{};
+            a.A = L + (long)(C0 * 128) * ld + Ka * 128; a.lda = ld; a.B = a.A; a.ldb = ld;
+            a.C = L + (long)(C0 * 128) * ld + C0 * 128; a.ldc = ld;
+            a.M = n - C0 * 128; a.N = (C1 - C0) * 128; a.K = (Kb - Ka) * 128; a.alpha = -1.0; a.beta = 1.0; a.lower_only = 0;
+            a.kmode = KMODE_FULL;
+            return gemm_f64(st, LAY_KC, LAY_KC, a);
+        };
+        auto next_end = [&](int K) { return (K + width(K) < nb) ? K + width(K) : nb; };
+        if (K1 < nb) {   // (a)_0 on the update stream, as there is no (b1) before it
+            HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
+            HIPCHK(rect(su, K0, K1, K1, next_end(K1)));
+            hipEvent_t e = next_event();
+            HIPCHK(hipEventRecord(e, su));
+            HIPCHK(hipStreamWaitEvent(sp, e, 0));
+        }
+        while (K1 < nb) {
+            const int K2 = next_end(K1);
+            HIPCHK(panel(sp, K1, K2));                       // its columns carry every earlier panel's update by now
+            hipEvent_t e_next = next_event();
+            HIPCHK(hipEventRecord(e_next, sp));
+            if (K2 < nb) {
+                const int K3 = next_end(K2);
+                HIPCHK(hipStreamWaitEvent(su, e_panel, 0));  // L_k = panel [K0,K1) is complete
+                HIPCHK(rect(su, K0, K1, K2, K3));            // (b1)_k
+                hipEvent_t e_b1 = next_event();
+                HIPCHK(hipEventRecord(e_b1, su));
+                const int rows = n - K3 * 128;
+                if (rows > 0 && K3 < nb) {                   // (b2)_k
+                    const int Kw = (K1 - K0) * 128;
+                    GemmArgs u{};
+                    u.A = L + (long)(K3 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
+                    u.C = L + (long)(K3 * 128) * ld + K3 * 128; u.ldc = ld;
+                    u.M = rows; u.N = rows; u.K = Kw; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
+                    static const bool no_maps = getenv("JAICOV_NO_XCD_MAP") != nullptr;
+                    if (xcd_maps && !no_maps && rows / 128 >= 24) {
+                        auto it = tile_maps.find(rows / 128);
+                        if (it != tile_maps.end()) { u.tile_map = it->second.first; u.n_map = it->second.second; }
+                    }
+                    HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
+                }
+                HIPCHK(hipStreamWaitEvent(sp, e_b1, 0));
+                HIPCHK(rect(sp, K1, K2, K2, K3));            // (a)_{k+1}, behind panel [K1,K2) on its stream
+            }
+            e_panel = e_next;
+            K0 = K1;
+            K1 = K2;
+        }
+    }
     while (K1 < nb) {
         const int K2 = (K1 + width(K1) < nb) ? K1 + width(K1) : nb;     // end of the next panel
         if (la) HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
