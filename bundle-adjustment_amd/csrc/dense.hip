@@ -475,7 +475,8 @@ hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
         // ... except for the first block of a panel: it becomes ready at the moment the trailing update is launched, and a
         // workgroup that wants a whole CU's LDS then waits for the update's first tiles to retire (130 us instead of 49)
         static const bool first_split = !(getenv("JAICOV_TAIL_FIRST_SPLIT") && atoi(getenv("JAICOV_TAIL_FIRST_SPLIT")) == 0);
-        const bool split = dstream != nullptr && st == pstream && (rows_k > tail_rows || (first_split && k == K0));
+        // (only while the update still has more workgroups than the chip has slots: 31 tile rows = 496 tiles)
+        const bool split = dstream != nullptr && st == pstream && (rows_k > tail_rows || (first_split && k == K0 && rows_k > 4096));
         // While the trailing update still hides the panel (many rows left) the panel GEMMs take the 128-tile: it costs
         // the update fewer CU slots per flop than the 64-tile latency variant, which is for the critical-path regime.
         static const int bulk_rows = getenv("JAICOV_BULK_ROWS") ? atoi(getenv("JAICOV_BULK_ROWS")) : 9216;
