@@ -53,7 +53,11 @@ struct DenseSolver {
     void release();
     hipError_t panel(hipStream_t st, int K0, int K1);
     hipError_t timed_gemm(hipStream_t st, const GemmArgs &u, double flops, int small = 0);
-    hipError_t potrf();                                     // L <- chol(L); info via fetch_info()
+    // L <- chol(L); info via fetch_info().  first_ready / all_ready (optional, events on `stream`): the first panel's
+    // columns [0, first_panel_cols()) resp. the whole matrix are in place -- the first panel then factors while the
+    // caller is still filling the rest.
+    hipError_t potrf(hipEvent_t first_ready = nullptr, hipEvent_t all_ready = nullptr);
+    int first_panel_cols() const;
     hipError_t backsolve_aug(double *X, long xs, int nrhs);  // L' X = Z, Z = the rhs rows after potrf(); X rows have stride xs
     hipError_t trtri();                                     // W <- L^-1
     hipError_t lauum();                                     // Q <- W' W (lower tiles)

@@ -533,7 +533,17 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
     return hipSuccess;
 }
 
-hipError_t DenseSolver::potrf() {
+int DenseSolver::first_panel_cols() const {
+    const int nb = nfact / 128;
+    int w = getenv("JAICOV_NBO") ? atoi(getenv("JAICOV_NBO")) : nbo;
+    const int big_rows = getenv("JAICOV_NBO_BIG_ROWS") ? atoi(getenv("JAICOV_NBO_BIG_ROWS")) : 1 << 30;
+    const int small_rows = getenv("JAICOV_NBO_SMALL_ROWS") ? atoi(getenv("JAICOV_NBO_SMALL_ROWS")) : 0;
+    const int bo = w / 128 > 0 ? w / 128 : 1;
+    const int k = n > big_rows ? 2 * bo : (n > small_rows ? bo : (bo > 1 ? bo / 2 : 1));
+    return 128 * (k < nb ? k : nb);
+}
+
+hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
     const int nb = nfact / 128;   // diagonal blocks; rows run to n (the right-hand-side rows below the matrix included)
     if (const char *e = getenv("JAICOV_NBO")) nbo = atoi(e);
     // Panel width: wide panels (K = 2 nbo) make the trailing update more efficient while it dominates (many rows left),
@@ -545,7 +555,6 @@ hipError_t DenseSolver::potrf() {
         const int rows = n - K * 128;
         return rows > big_rows ? 2 * bo : (rows > small_rows ? bo : (bo > 1 ? bo / 2 : 1));
     };
-    HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
     static const bool no_la = getenv("JAICOV_NO_LOOKAHEAD") != nullptr;
     const bool la = lookahead && !no_la && pstream != nullptr && nb > bo;
     ev_used = 0;
@@ -553,10 +562,16 @@ hipError_t DenseSolver::potrf() {
     hipStream_t su = la && ustream ? ustream : stream;      // trailing updates (all CUs but the reserved ones)
     hipEvent_t e_start = next_event();
     if (la) {
-        HIPCHK(hipEventRecord(e_start, stream));
-        HIPCHK(hipStreamWaitEvent(sp, e_start, 0));
-        if (su != stream) HIPCHK(hipStreamWaitEvent(su, e_start, 0));
+        if (first_ready && all_ready) {                     // the caller is still filling the columns behind the first panel
+            HIPCHK(hipStreamWaitEvent(sp, first_ready, 0));
+            if (su != stream) HIPCHK(hipStreamWaitEvent(su, all_ready, 0));
+        } else {
+            HIPCHK(hipEventRecord(e_start, stream));
+            HIPCHK(hipStreamWaitEvent(sp, e_start, 0));
+            if (su != stream) HIPCHK(hipStreamWaitEvent(su, e_start, 0));
+        }
     }
+    HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), sp));    // before the first diagonal kernel, which runs on sp or behind it
     int K0 = 0, K1 = width(0) < nb ? width(0) : nb;
     HIPCHK(panel(sp, 0, K1));
     hipEvent_t e_panel = next_event();

@@ -68,10 +68,10 @@ __global__ __launch_bounds__(256) void zero_lower_kernel(double *__restrict__ N,
 // M = V N V + Bh' Bh on the unknown block (lower part), identity on border and padding.  Bh: [d][bstride]
 __global__ __launch_bounds__(256) void scale_copy_kernel(const double *__restrict__ N, long ldN, double *__restrict__ M,
                                                          long ld, int U, int Upad, int d, const double *__restrict__ V,
-                                                         const double *__restrict__ Bh, int bstride) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+                                                         const double *__restrict__ Bh, int bstride, int c_begin, int c_end) {
+    const int j = c_begin + blockIdx.x * 256 + threadIdx.x;   // columns [c_begin, c_end)
     const int i = blockIdx.y;
-    if (j > i || j >= Upad) return;
+    if (j > i || j >= c_end) return;
     double v;
     if (i < d || i >= U || j < d) v = (i == j) ? 1.0 : 0.0;
     else {
@@ -201,6 +201,7 @@ struct jaicov_engine {
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[10];
+    hipEvent_t ev_first = nullptr, ev_all = nullptr;   // solve(): first panel's columns / whole matrix copied into the solver
 };
 
 #define FAIL(e, code, msg)                 \
@@ -278,6 +279,8 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     for (void *ptr : e->allocs) hipFree(ptr);
     for (auto &evt : e->ev)
         if (evt) hipEventDestroy(evt);
+    if (e->ev_first) hipEventDestroy(e->ev_first);
+    if (e->ev_all) hipEventDestroy(e->ev_all);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -294,6 +297,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
         FAIL(e, JAICOV_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     HIPE(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto &evt : e->ev) HIPE(e, hipEventCreate(&evt));
+    HIPE(e, hipEventCreateWithFlags(&e->ev_first, hipEventDisableTiming));
+    HIPE(e, hipEventCreateWithFlags(&e->ev_all, hipEventDisableTiming));
 
     const int U = D->n_unknowns, d = D->rank_defect;
     e->U = U; e->d = d; e->datum_flags = D->datum_flags;
@@ -959,8 +964,11 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     if (d > 0) HIPE(e, hipMemcpyAsync(e->d_B, Bh.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPE(e, hipEventRecord(e->ev[4], e->stream));
-    hipLaunchKernelGGL(scale_copy_kernel, dim3((Up + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
-                       Up, d, e->d_V, e->d_B, Upad);
+    // The columns of the first panel go first, together with the right-hand sides; the panel then factors on its stream
+    // while the rest of the matrix is still being scaled and copied (0.4 ms at config 4).
+    const int c1 = std::min(slv.first_panel_cols(), Up);
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
+                       Up, d, e->d_V, e->d_B, Upad, 0, c1);
     // right-hand sides: row 0 = V n, rows 1..d = Bh.  They are the extra rows below the matrix, so the factorisation
     // itself carries out the forward substitution (dense.hip).
     const int vs = Up;   // stride between the solution vectors (the solver's order)
@@ -969,7 +977,12 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     if (d > 0)
         HIPE(e, hipMemcpy2DAsync(slv.rhs_row(1), (size_t)ld * sizeof(double), e->d_B, (size_t)Upad * sizeof(double),
                                  (size_t)Up * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, e->stream));
-    HIPE(e, slv.potrf());
+    HIPE(e, hipEventRecord(e->ev_first, e->stream));
+    if (c1 < Up)
+        hipLaunchKernelGGL(scale_copy_kernel, dim3((Up - c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L,
+                           ld, U, Up, d, e->d_V, e->d_B, Upad, c1, Up);
+    HIPE(e, hipEventRecord(e->ev_all, e->stream));
+    HIPE(e, slv.potrf(e->ev_first, e->ev_all));
     HIPE(e, hipEventRecord(e->ev[5], e->stream));
     HIPE(e, slv.backsolve_aug(e->d_G, vs, nrhs));           // G <- L^-T (L^-1 Y)   (row 0: y~, rows 1..d: G^)
     HIPE(e, hipEventRecord(e->ev[6], e->stream));
