@@ -933,12 +933,6 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     slv.profile = e->solver.profile;
     const int Up = slv.nfact;                      // padded order of the factorised system
     const long ld = slv.ld;
-    if (schur) {
-        int hinfo = 0;
-        HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPE(e, hipStreamSynchronize(e->stream));
-        if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
-    }
     bool &has_inv = schur ? e->solverS_has_inverse : e->solver_has_inverse;
     if (invert && !has_inv) {
         const size_t sq = (size_t)slv.n * slv.ld * sizeof(double);
@@ -948,7 +942,10 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
     HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    int hinfo = 0;   // status of the per-image EO eliminations, fetched in the same round trip
+    if (schur) HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPE(e, hipStreamSynchronize(e->stream));
+    if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
     std::vector<double> Bh((size_t)8 * Upad, 0.0);
     double R[7] = {1, 1, 1, 1, 1, 1, 1};
     for (int a = 0; a < d; a++) {
