@@ -361,7 +361,7 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     const int cp0 = p.point_col[3 * pt], cp1 = p.point_col[3 * pt + 1], cp2 = p.point_col[3 * pt + 2];
     const int rmax = max(cp0, max(cp1, cp2));
     const int ob = pp.pt_ip_begin[pt], oe = pp.pt_ip_begin[pt + 1];
-    if (rmax < c0 || ob == oe) return;
+    if (rmax < c0 || (ob == oe && !(pp.plain && rmax <= pp.cmax))) return;   // plain mode: an unobserved point stores zeros
     const int2 *range = reinterpret_cast<const int2 *>(pp.range);
     for (int i = tid; i < 3 * PP_CW; i += PP_NT) strip[i] = 0.0;
     __syncthreads();
@@ -405,9 +405,13 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
         if (r < 0) continue;
         const int cend = min(PP_CW, r - c0 + 1);
         double *nrow = N + (long)r * p.ld + c0;
-        for (int c = tid; c < cend; c += PP_NT) {
-            const double v = strip[a * PP_CW + c];
-            if (v != 0.0) nrow[c] += v;
+        if (pp.plain) {
+            for (int c = tid; c < cend; c += PP_NT) nrow[c] = strip[a * PP_CW + c];
+        } else {
+            for (int c = tid; c < cend; c += PP_NT) {
+                const double v = strip[a * PP_CW + c];
+                if (v != 0.0) nrow[c] += v;
+            }
         }
     }
 }

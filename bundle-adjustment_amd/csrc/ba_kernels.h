@@ -60,6 +60,9 @@ struct PPGather {
     // only the lower triangle is assembled)
     const int32_t *range = nullptr;
     int cmin = 0, n_chunks = 0;
+    // plain != 0: the rows cmin..cmax of N are point rows only and nobody else has written their columns >= cmin yet;
+    // the strips are then STORED (zeros included) instead of added, which saves zeroing that part of N and reading it back
+    int cmax = -1, plain = 0;
 };
 
 // buffers of the per-image EO pre-elimination (schur.hip); Pp == nullptr -> mode off

@@ -59,9 +59,17 @@ __global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int
 }
 
 // zero the lower triangle (row r: columns 0 .. r, rounded up to 4) of the leading `rows` rows; grid (ceil(rows/1024), rows)
-__global__ __launch_bounds__(256) void zero_lower_kernel(double *__restrict__ N, long ld, int rows) {
+// rows skip_lo..skip_hi (the point rows the gather stores itself, PPGather::plain): only the columns before skip_lo
+__global__ __launch_bounds__(256) void zero_lower_kernel(double *__restrict__ N, long ld, int rows, int skip_lo, int skip_hi) {
     const int r = blockIdx.y, c = 4 * (blockIdx.x * 256 + threadIdx.x);
     if (c > r) return;
+    if (r >= skip_lo && r <= skip_hi) {
+        if (c >= skip_lo) return;
+        if (c + 4 > skip_lo) {           // the quad straddles the first stored column
+            for (int k = c; k < skip_lo; k++) N[(long)r * ld + k] = 0.0;
+            return;
+        }
+    }
     *reinterpret_cast<d4_t *>(N + (long)r * ld + c) = (d4_t){0.0, 0.0, 0.0, 0.0};
 }
 
@@ -201,6 +209,7 @@ struct jaicov_engine {
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[10];
+    bool pp_plain_ok = false;   // the point x point gather may store its strips (see PPGather::plain)
     hipEvent_t ev_first = nullptr, ev_all = nullptr;   // solve(): first panel's columns / whole matrix copied into the solver
 };
 
@@ -545,6 +554,17 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = upload(e, range.data(), range.size(), &e->pp.range))) return rc;
             e->pp.cmin = cmin;
             e->pp.n_chunks = n_chunks;
+            e->pp.cmax = cmax;
+            {   // rows cmin..cmax all point rows?  (points are numbered first and contiguously, BA:667-782)
+                std::vector<char> is_pt(cmax - cmin + 1, 0);
+                for (int i = 0; i < 3 * D->n_points; i++) {
+                    const int c = D->point_col[i];
+                    if (c >= cmin && c <= cmax) is_pt[c - cmin] = 1;
+                }
+                bool all = true;
+                for (char f : is_pt) all = all && f;
+                e->pp_plain_ok = all && !getenv("JAICOV_PP_RMW");
+            }
         }
     }
 
@@ -723,12 +743,17 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     if (rc) return rc;
     HIPE(e, hipEventRecord(e->ev[1], e->stream));
     e->schur_active = e->schur_ok && e->inverse_mode_next != JAICOV_INVERT_FULL;
+    // The point x point gather owns every entry of rows cmin..cmax from column cmin on: when it runs before everything
+    // else that adds into that region it stores its strips, and the region needs neither zeroing nor reading back.
+    const bool plain = e->pp_plain_ok && !e->dense_mode && e->pp.pt_ip_begin != nullptr && e->n_blk_list > 0;
     {   // only the lower triangle of N is ever written or read (nadd, pack, scale_copy); the reduced system has e0 rows
         const int rows = e->schur_active ? std::min(e->Upad, ((e->e0 + 127) / 128) * 128) : e->Upad;
-        hipLaunchKernelGGL(zero_lower_kernel, dim3((rows + 1023) / 1024, rows), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, rows);
+        hipLaunchKernelGGL(zero_lower_kernel, dim3((rows + 1023) / 1024, rows), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, rows,
+                           plain ? e->pp.cmin : rows, plain ? e->pp.cmax : -1);
         HIPE(e, hipMemsetAsync(e->d_N + sq, 0, (size_t)e->Upad * sizeof(double), e->stream));
     }
-    HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
+    if (!plain)
+        HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     SchurBufs sb = e->sb;
     if (!e->schur_active) sb.Pp = nullptr;
     sb.lambda = e->lambda_acc;
@@ -741,9 +766,14 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
         HIPE(e, e->dm.assemble(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n,
                                e->solver.profile ? &ms : nullptr));
         if (e->solver.profile) { e->dm_stat_passes += 1.0; e->dm_stat_ms += ms; e->dm_stat_flops += e->dm_flops_per_pass; }
-    } else
+    } else {
+        PPGather ppg = e->pp;
+        ppg.plain = plain ? 1 : 0;
         HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
-                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, e->pp, sb));
+                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, ppg, sb));
+    }
+    if (plain)   // the images outside the dense blocks come after the stores
+        HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, e->d_N, e->d_n, nullptr, nullptr));
     HIPE(e, hipEventRecord(e->ev[2], e->stream));
     e->state = jaicov_engine::ST_ACCUMULATED;
