@@ -263,6 +263,54 @@ __global__ __launch_bounds__(256) void blk_pc_kernel(DevProblem p, const int32_t
     }
 }
 
+// B3': the same sums without memory-side contention.  A (point, shared column) entry of N collects one term per image
+// that sees the point (50 at config 4), so the atomic version serialises on its hottest addresses (0.48 ms).  Here one
+// thread owns (point, local shared column c) and walks the point's incidences (the CSR of the point x point gather);
+// the target column only changes with the camera (c < 3, c >= 9) or with every image (EO, 3 <= c < 9), so the running
+// sums are flushed with an atomic whenever it changes -- once per point and column in the usual one-camera block.
+__global__ __launch_bounds__(256) void blk_pc_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
+                                                            const double *__restrict__ T, double sigma2,
+                                                            double *__restrict__ N, double *__restrict__ n, int schur) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const int pt = (int)(gid / KC_LD), c = (int)(gid - (long)pt * KC_LD);
+    if (pt >= p.n_points || (schur && c >= 3 && c < 9)) return;
+    const int ob = pp.pt_ip_begin[pt], oe = pp.pt_ip_begin[pt + 1];
+    if (ob == oe) return;
+    const long S = p.n_ip;
+    const int pc0 = p.point_col[3 * pt], pc1 = p.point_col[3 * pt + 1], pc2 = p.point_col[3 * pt + 2];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    int cur = -2;                     // target: -2 nothing pending, -1 skipped column, -3 the right-hand side, >= 0 column of N
+    auto flush = [&]() {
+        if (cur == -3) {
+            if (pc0 >= 0) unsafeAtomicAdd(n + pc0, s0);
+            if (pc1 >= 0) unsafeAtomicAdd(n + pc1, s1);
+            if (pc2 >= 0) unsafeAtomicAdd(n + pc2, s2);
+        } else if (cur >= 0) {
+            if (pc0 >= 0) nadd(N, p.ld, cur, pc0, s0);
+            if (pc1 >= 0) nadd(N, p.ld, cur, pc1, s1);
+            if (pc2 >= 0) nadd(N, p.ld, cur, pc2, s2);
+        }
+        s0 = s1 = s2 = 0.0;
+    };
+    for (int o = ob; o < oe; o++) {
+        const PPRecord r = pp.recs[o];
+        const int ip = r.ipb + r.lp;
+        const int img = p.ip_image[ip], cam = p.image_camera[img];
+        const int jb = p.cam_dist_begin[cam], kc = 9 + p.cam_dist_begin[cam + 1] - jb;
+        int tgt;
+        if (c > kc) tgt = -1;
+        else if (c == kc) tgt = -3;
+        else { tgt = shared_col(p, img, cam, jb, c); if (tgt < 0) tgt = -1; }
+        if (tgt != cur) { flush(); cur = tgt; }
+        if (tgt == -1) continue;
+        const double t0 = T[((long)2 * ip) * KC_LD + c], t1 = T[((long)2 * ip + 1) * KC_LD + c];
+        s0 += sigma2 * (rowsA[ip] * t0 + rowsA[S + ip] * t1);
+        s1 += sigma2 * (rowsA[2 * S + ip] * t0 + rowsA[3 * S + ip] * t1);
+        s2 += sigma2 * (rowsA[4 * S + ip] * t0 + rowsA[5 * S + ip] * t1);
+    }
+    flush();
+}
+
 // B4: point x point blocks: N[pt_p, pt_q] += A_p' Dinv[rows p, rows q] A_q * sigma2, q <= p within the block.
 // One thread per (q, b): it owns COLUMN b of the 3x3 block and issues one atomic per row a, so the three lanes of a
 // point write 24 contiguous bytes of one row of N in a single wave instruction (one memory-side atomic request
@@ -601,8 +649,13 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     }
     hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, 8), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
-    hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
-                       ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
+    static const bool pc_atomic = getenv("JAICOV_PC_ATOMIC") != nullptr;
+    if (pp.pt_ip_begin && !pc_atomic) {
+        const long totp = (long)p.n_points * KC_LD;
+        hipLaunchKernelGGL(blk_pc_gather_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0, s, p, pp, rowsA, T, s2, N, n, schur);
+    } else
+        hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
+                           ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
     if (pp.pt_ip_begin) {
         hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp, rowsA, s2, N);
     } else {
