@@ -1,6 +1,8 @@
 // Normal-equation assembly N += A'PA, n += A'Pw (PDF:475-505 stackNormalEquationSystem) from the compact rows,
 // structure-aware: the shared camera/EO blocks of an image are reduced on chip (LDS) before they touch HBM, only the
 // point-indexed blocks go out as fp64 atomics.  N is row-major LOWER (== UPLO='U' column-major).  gfx950 only.
+#include <algorithm>
+#include <cstdlib>
 #include "ba_kernels.h"
 #include "gemm_f64.h"
 
@@ -647,7 +649,8 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         q.blk_w = sb.Pp;
         s2 = 1.0;
     }
-    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, 8), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
+    static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::max(1, atoi(getenv("JAICOV_CC_PARTS"))) : 8;
+    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
     static const bool pc_atomic = getenv("JAICOV_PC_ATOMIC") != nullptr;
     if (pp.pt_ip_begin && !pc_atomic) {
