@@ -47,6 +47,22 @@ struct DenseSolver {
     size_t prof_used = 0;
     double stat_launches = 0, stat_ms = 0, stat_flops = 0;
     void prof_collect();                 // call after the stream has been synchronised
+    double flops_order = 0;              // real (unpadded) order of the matrix, for the algorithmic flop count n^3/3; 0 = nfact
+
+    // dataflow factorisation (cholflow.hip): the whole potrf as two concurrent launches, dependencies as flags in memory
+    bool flow_ready = false, flow_timed = false;
+    int4 *flow_task_list = nullptr;
+    int flow_tasks = 0, flow_fs = 0, flow_grid = 0;
+    int *flow_flags = nullptr;           // control words, done / applied flags, diag_ready
+    size_t flow_words = 0;
+    double *flow_scratch = nullptr;
+    long long *flow_trace = nullptr;
+    hipEvent_t flow_e0 = nullptr, flow_e1 = nullptr, flow_e2 = nullptr, flow_t0 = nullptr, flow_t1 = nullptr;
+    hipError_t flow_init();
+    void flow_release();
+    hipError_t potrf_flow(hipEvent_t all_ready);
+    hipError_t potrf_streams(hipEvent_t first_ready, hipEvent_t all_ready);   // the stream / event scheduled factorisation
+    hipError_t flow_enable_trace(bool on);
 
     hipError_t init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows = false);
     double *rhs_row(int q) const { return L + (long)(nfact + q) * ld; }   // row q of the right-hand sides / of Z = Y L^-T
@@ -62,7 +78,7 @@ struct DenseSolver {
     hipError_t trtri();                                     // W <- L^-1
     hipError_t lauum();                                     // Q <- W' W (lower tiles)
     hipError_t symmetrize(double *M);                       // copy lower -> upper
-    int fetch_info();                                       // synchronises the stream
+    int fetch_info();                                       // synchronises the stream; > 0 failing pivot, -9 dataflow stalled
 };
 
 }  // namespace jaicov

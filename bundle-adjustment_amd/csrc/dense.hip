@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include "gemm_f64.h"
+#include "potrf_diag.h"
 
 namespace jaicov {
 
@@ -15,203 +16,10 @@ namespace jaicov {
         if (_e != hipSuccess) return _e;           \
     } while (0)
 
-// ---------------------------------------------------------------------------------------------------------------
-// Diagonal block: Cholesky of a 128x128 SPD block held in LDS by one workgroup (4 waves), plus the inverse of its
-// factor.  A (global, lower part) <- L ; inv_out (128x128 row-major, zeros above the diagonal) <- L^-1.
-//
-// Blocked with 16-wide panels: the 16x16 diagonal block is factored AND inverted in the registers of wave 0
-// (lane i = row i, operands broadcast with v_readlane), the panel solve and the trailing update run as
-// v_mfma_f64_16x16x4 tile products straight out of LDS (row stride 129 doubles: conflict-free fragment reads).
-// The inverse is built diagonal by diagonal: W[I][J] = -Wdd[I] * sum_{K=J}^{I-1} L[I][K] W[K][J]; the accumulator
-// of the first product IS the B fragment of the second (C/D rows (l>>4)+4r == B rows 4ks+(l>>4)), so it never
-// leaves the registers.  Off-diagonal W tiles are parked transposed in the (unused) strict upper part of S.
-// ---------------------------------------------------------------------------------------------------------------
-constexpr int DP = 129;   // padded LDS row
-constexpr int WDP = 17;   // padded row of the 16x16 diagonal-block inverses
-
-// broadcast from a wave-uniform lane: two v_readlane_b32 (scalar path) instead of ds_bpermute round trips
-__device__ __forceinline__ double bcast(double v, int src_lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
-
-// 16x16 Cholesky + inverse of the diagonal block at (c0,c0) in the registers of ONE wave (lane i < 16 = row i).
-// The reciprocal square root replaces sqrt + divide on the 128-step critical path (v_rsq_f64 + Newton, ~1 ulp).
-__device__ __forceinline__ void chol16_inv(double *S, double *Wd_p, int c0, int lane, int *info, int blk) {
-    const int l15 = lane & 15;
-    double a[16], x[16], rinv[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) a[k] = S[(c0 + l15) * DP + c0 + k];
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-        double d = bcast(a[j], j);
-        if (!(d > 0.0)) {   // not positive definite (also NaN): MatrixNotSPDException / info > 0
-            if (lane == 0) atomicCAS(info, 0, blk * 128 + c0 + j + 1);
-            d = 1.0;
-        }
-        double rl = rsqrt(d);
-        rl = rl * (1.5 - 0.5 * d * rl * rl);         // one more Newton step: full fp64 accuracy
-        const double ljj = d * rl;
-        rinv[j] = rl;
-        a[j] = (l15 == j) ? ljj : a[j] * rl;
-        // column j of L goes to LDS; the next column, which the following step waits for, gets its multiplier by
-        // v_readlane (short latency), the other 14-j columns read theirs back from LDS as broadcast loads (pipelined)
-        if (lane < 16 && lane >= j) S[(c0 + lane) * DP + c0 + j] = a[j];
-        if (j + 1 < 16) a[j + 1] -= a[j] * bcast(a[j], j + 1);
-#pragma unroll
-        for (int k = j + 2; k < 16; k++) a[k] -= a[j] * S[(c0 + k) * DP + c0 + j];
-    }
-    // the factor is in LDS now: the inverse below reads L[i][k] from there as wave-uniform (broadcast) loads, which the
-    // hardware pipelines, instead of 120 v_readlane pairs on the scalar path
-    // X = L^-1 by forward substitution, lane c holds column c; column-oriented so that the 15-k updates that follow
-    // x[k] are independent of each other (the dependent chain is 16 links, not 120)
-    double sres[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) sres[i] = (l15 == i) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        x[k] = sres[k] * rinv[k];
-#pragma unroll
-        for (int i = k + 1; i < 16; i++) sres[i] -= S[(c0 + i) * DP + c0 + k] * x[k];
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int k = 0; k < 16; k++) Wd_p[k * WDP + lane] = x[k];          // Wdd[row k][col lane]
-    }
-}
-
-// trailing-update tile (R,Q) of panel p:  S[R][Q] -= S[R][p] S[Q][p]'
-__device__ __forceinline__ void diag_update_tile(double *S, int R, int Q, int c0, int l15, int l4) {
-    d4_t acc;
-#pragma unroll
-    for (int r = 0; r < 4; r++) acc[r] = S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15];
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-        const double av = -S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
-        const double bv = S[(16 * Q + l15) * DP + c0 + 4 * ks + l4];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15] = acc[r];
-}
-
-// inv_out must be zero above the diagonal on entry (the buffer is zero-filled once at allocation).
 __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, double *inv_out, int *info, int blk, int dbg) {
     __shared__ double S[128 * DP];
     __shared__ double Wd[8 * 16 * WDP];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // block -> LDS: 16 independent 16-byte loads in flight per thread (a rolled load->store loop serialises on the
-    // memory latency: 64 round trips, ~45 us)
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        d2_t buf[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int idx2 = tid + 256 * (16 * half + i);
-            buf[i] = *reinterpret_cast<const d2_t *>(A + (long)(idx2 >> 6) * ld + 2 * (idx2 & 63));
-        }
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int idx2 = tid + 256 * (16 * half + i);
-            const int r = idx2 >> 6, c = 2 * (idx2 & 63);
-            S[r * DP + c] = (c <= r) ? buf[i].x : 0.0;
-            S[r * DP + c + 1] = (c + 1 <= r) ? buf[i].y : 0.0;
-        }
-    }
-    __syncthreads();
-    if (wave == 0 && !(dbg & 1)) chol16_inv(S, Wd, 0, lane, info, blk);
-    __syncthreads();
-    for (int p = 0; p < 8; p++) {
-        if (dbg & 2) break;
-        const int c0 = 16 * p;
-        // ---- panel solve: L21 = A21 * Wdd' for the row tiles below ------------------------------------------
-        for (int R = p + 1 + wave; R < 8; R += 4) {
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const double av = S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
-                const double bv = Wd[p * 16 * WDP + l15 * WDP + 4 * ks + l4];   // B[k][j] = Wdd[j][k]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + c0 + l15] = acc[r];
-        }
-        __syncthreads();
-        if (p == 7) break;
-        // ---- phase A: block column p+1 of the trailing update (the next diagonal block and its panel) ----------
-        for (int R = p + 1 + wave; R < 8; R += 4) diag_update_tile(S, R, p + 1, c0, l15, l4);
-        __syncthreads();
-        // ---- phase B: wave 0 factors the next diagonal block while waves 1-3 finish the trailing update ----
-        if (wave == 0) {
-            if (!(dbg & 1)) chol16_inv(S, Wd + (p + 1) * 16 * WDP, 16 * (p + 1), lane, info, blk);
-        } else {
-            const int rem = 6 - p, nt = rem * (rem + 1) / 2;     // tiles (R,Q), p+2 <= Q <= R <= 7
-            for (int t = wave - 1; t < nt; t += 3) {
-                int rr = 0;
-                while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
-                diag_update_tile(S, p + 2 + rr, p + 2 + (t - rr * (rr + 1) / 2), c0, l15, l4);
-            }
-        }
-        __syncthreads();
-    }
-    // factor back to global (lower part; the strict upper part of a diagonal block is never read by anyone)
-#pragma unroll 8
-    for (int i = 0; i < 32; i++) {
-        const int idx2 = tid + 256 * i;
-        const int r = idx2 >> 6, c = 2 * (idx2 & 63);
-        if (c <= r) {
-            d2_t v;
-            v.x = S[r * DP + c];
-            v.y = S[r * DP + c + 1];
-            *reinterpret_cast<d2_t *>(A + (long)r * ld + c) = v;
-        }
-    }
-    // ---- inverse, one block diagonal after the other ---------------------------------------------------------
-    for (int t = 1; t < 8; t++) {
-        if (dbg & 4) break;
-        for (int J = wave; J < 8 - t; J += 4) {
-            const int I = J + t;
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {   // K = J: L[I][J] * Wdd[J]
-                const double av = S[(16 * I + l15) * DP + 16 * J + 4 * ks + l4];
-                const double bv = Wd[J * 16 * WDP + (4 * ks + l4) * WDP + l15];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-            for (int K = J + 1; K < I; K++) {
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const double av = S[(16 * I + l15) * DP + 16 * K + 4 * ks + l4];
-                    const double bv = S[(16 * J + l15) * DP + 16 * K + 4 * ks + l4];   // W[K][J] parked transposed
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-            }
-            d4_t acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const double av = Wd[I * 16 * WDP + l15 * WDP + 4 * ks + l4];
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, acc[ks], acc2, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[(16 * J + l15) * DP + 16 * I + l4 + 4 * r] = -acc2[r];
-        }
-        __syncthreads();
-    }
-#pragma unroll 8
-    for (int i = 0; i < 32; i++) {
-        const int idx2 = tid + 256 * i;
-        const int r = idx2 >> 6, c = 2 * (idx2 & 63);
-        if (c <= r) {
-            d2_t v;
-            v.x = ((r >> 4) == (c >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + (c & 15)] : S[c * DP + r];
-            v.y = (c + 1 > r) ? 0.0
-                              : (((r >> 4) == ((c + 1) >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + ((c + 1) & 15)]
-                                                              : S[(c + 1) * DP + r]);
-            *reinterpret_cast<d2_t *>(inv_out + r * 128 + c) = v;
-        }
-    }
+    potrf_diag_body(A, ld, inv_out, info, blk, dbg, S, Wd);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -392,7 +200,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask is CU i/8 of XCD i%8): the trailing
         // updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.  (Reserving fewer CUs was
         // measured: one or two reserved CUs cost 5 ms per factorisation at config 4, eight cost the update 3 % of the chip.)
-        if (nfact >= 2048 && !getenv("JAICOV_NO_CUMASK")) {
+        static const bool legacy = getenv("JAICOV_POTRF_LEGACY") != nullptr;
+        if ((nfact >= 2048 || !legacy) && !getenv("JAICOV_NO_CUMASK")) {
             uint32_t upd[8], dia[8];
             for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
             upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u;
@@ -424,11 +233,16 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
     }
+    if (!getenv("JAICOV_POTRF_LEGACY") && ustream && dstream) {
+        hipError_t fe = flow_init();
+        if (fe != hipSuccess) { flow_release(); (void)hipGetLastError(); }   // the stream-scheduled factorisation remains
+    }
     return hipSuccess;
 }
 
 void DenseSolver::release() {
     if (!owns) return;
+    flow_release();
     hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q);
     hipFree(tile_map_store);
     tile_map_store = nullptr;
@@ -544,6 +358,11 @@ int DenseSolver::first_panel_cols() const {
 }
 
 hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
+    if (flow_ready) return potrf_flow(all_ready);
+    return potrf_streams(first_ready, all_ready);
+}
+
+hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_ready) {
     const int nb = nfact / 128;   // diagonal blocks; rows run to n (the right-hand-side rows below the matrix included)
     if (const char *e = getenv("JAICOV_NBO")) nbo = atoi(e);
     // Panel width: wide panels (K = 2 nbo) make the trailing update more efficient while it dominates (many rows left),
@@ -762,12 +581,25 @@ void DenseSolver::prof_collect() {
     }
     prof_used = 0;
     prof_flops.clear();
+    if (flow_timed) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, flow_t0, flow_t1) == hipSuccess) {
+            const double o = flops_order > 0 ? flops_order : (double)nfact;
+            stat_launches += 1.0;
+            stat_ms += ms;
+            stat_flops += o * o * o / 3.0;
+        }
+        flow_timed = false;
+    }
 }
 
 int DenseSolver::fetch_info() {
     int h = -1;
     if (hipMemcpyAsync(&h, d_info, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    int ab = 0;
+    if (flow_ready && hipMemcpyAsync(&ab, flow_flags + 1, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
+    if (ab != 0) return -9;   // a wait of the dataflow factorisation ran into its time limit
     return h;
 }
 

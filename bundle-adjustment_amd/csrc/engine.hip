@@ -205,6 +205,7 @@ struct jaicov_engine {
     bool solver_has_inverse = false;
     enum { ST_NEW, ST_PARAMS, ST_ACCUMULATED, ST_BUILT, ST_SOLVED } state = ST_NEW;
     bool have_Q = false, rows_valid = false, reduced = false;
+    bool sim_built = false;      // the system at hand was built with simulation != 0: the right-hand side is zero for ALL unknowns (BA:830-831)
     double lambda_used = 0.0;
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -270,6 +271,7 @@ static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_
     HIPE(e, ds.lauum());
     hipLaunchKernelGGL(store_inv_kernel, dim3((m + 255) / 256, m), dim3(256), 0, e->stream, ds.Q, ds.ld, m, d_out);
     const int info = ds.fetch_info();
+    if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation of a dispersion matrix did not complete on the device (code " + std::to_string(info) + ")");
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)");
     return JAICOV_OK;
 }
@@ -737,6 +739,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
     if (!(sigma2 > 0)) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "variance of unit weight must be positive (DOPG:68-69)");
     HIPE(e, hipSetDevice(e->device));
+    e->reduced = false;          // a packed buffer of an earlier accumulate must not be unpacked over this one
     const size_t sq = (size_t)e->Upad * e->Upad;
     HIPE(e, hipEventRecord(e->ev[0], e->stream));
     int rc = ensure_rows(e);
@@ -845,6 +848,7 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
                        e->schur_active ? e->e0 : e->U, e->Upad, e->d, lambda > 0 ? lambda : 0.0, e->d_V,
                        e->schur_active ? e->sb.diagcorr : nullptr);
     if (simulation) HIPE(e, hipMemsetAsync(e->d_n, 0, e->Upad * sizeof(double), e->stream));   // BA:830-831
+    e->sim_built = simulation != 0;
     HIPE(e, hipEventRecord(e->ev[3], e->stream));
     e->lambda_used = lambda;
     e->state = jaicov_engine::ST_BUILT;
@@ -961,6 +965,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     DenseSolver &slv = schur ? e->solverS : e->solver;
     slv.profile = e->solver.profile;
+    slv.flops_order = (double)(schur ? e->e0 : e->U);
     const int Up = slv.nfact;                      // padded order of the factorised system
     const long ld = slv.ld;
     bool &has_inv = schur ? e->solverS_has_inverse : e->solver_has_inverse;
@@ -1016,6 +1021,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     std::vector<double> X((size_t)nrhs * vs);
     HIPE(e, hipMemcpyAsync(X.data(), e->d_G, X.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
     const int info = slv.fetch_info();
+    if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation did not complete on the device (code " + std::to_string(info) + ")");
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "normal-equation matrix is singular / not positive definite at pivot " + std::to_string(info));
     // ---- rank-d border algebra on the host ---------------------------------------------------------------------
     double Sm[49], Sinv[49], kh[7];
@@ -1048,7 +1054,11 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     for (int c = 0; c < U; c++) dx_out[c] = c < d ? R[c] * kh[c] : e->h_V[c] * y[c];
     for (int c = 0; c < U; c++)
         if (!std::isfinite(dx_out[c])) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite step");
-    if (schur) {
+    if (schur && e->sim_built) {
+        // SIMULATION zeroes the right-hand side of the WHOLE system (BA:830-831 `n.zero()`): the eliminated exterior
+        // orientations get no step either (their back substitution would use the real misclosures)
+        for (int c = U; c < e->U; c++) dx_out[c] = 0.0;
+    } else if (schur) {
         // EO step of every image of this engine: dx_E = L_E^-T U' (w - A_r dx_R)   (schur.hip)
         for (int c = U; c < e->U; c++) dx_out[c] = 0.0;
         HIPE(e, hipMemcpyAsync(e->d_dx, dx_out, (size_t)e->U * sizeof(double), hipMemcpyHostToDevice, e->stream));
@@ -1163,18 +1173,25 @@ extern "C" int jaicov_neq_get_normal(jaicov_engine *e, double *N_packed, size_t 
     const int U = e->U;
     if (len != (size_t)U * (U + 1) / 2 || Ulen != (size_t)U) return JAICOV_ERR_BAD_ARGUMENT;
     HIPE(e, hipSetDevice(e->device));
+    // with the exterior orientations pre-eliminated only the reduced system (order e0) was assembled: the rows from e0 on
+    // of the square are neither zeroed nor written in such a pass.  The header's contract: reduced system in the leading
+    // e0 rows / columns, zeros elsewhere.
+    const int Ua = e->schur_active ? e->e0 : U;
+    const size_t lenA = (size_t)Ua * (Ua + 1) / 2;
     double *d_ap = nullptr;
-    HIPE(e, hipMalloc(&d_ap, std::max<size_t>(len, 1) * sizeof(double)));
-    hipLaunchKernelGGL(pack_kernel, dim3((U + 255) / 256, std::max(U, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, U, d_ap);
-    hipError_t he = hipMemcpyAsync(N_packed, d_ap, len * sizeof(double), hipMemcpyDeviceToHost, e->stream);
-    if (he == hipSuccess) he = hipMemcpyAsync(n, e->d_n, U * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    HIPE(e, hipMalloc(&d_ap, std::max<size_t>(lenA, 1) * sizeof(double)));
+    hipLaunchKernelGGL(pack_kernel, dim3((Ua + 255) / 256, std::max(Ua, 1)), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, Ua, d_ap);
+    hipError_t he = hipMemcpyAsync(N_packed, d_ap, lenA * sizeof(double), hipMemcpyDeviceToHost, e->stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(n, e->d_n, Ua * sizeof(double), hipMemcpyDeviceToHost, e->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
     hipFree(d_ap);
     HIPE(e, he);
+    if (lenA < len) memset(N_packed + lenA, 0, (len - lenA) * sizeof(double));
+    for (int c = Ua; c < U; c++) n[c] = 0.0;
     // the datum border lives on the host (rows 0..d-1): K[r][c] = B[r][c]  (BA:548-593), packed index r + c(c+1)/2
     if (e->state != jaicov_engine::ST_ACCUMULATED)
         for (int r = 0; r < e->d; r++)
-            for (int c = e->d; c < U; c++) N_packed[(size_t)r + (size_t)c * (c + 1) / 2] = e->hB[(size_t)r * e->Upad + c];
+            for (int c = e->d; c < Ua; c++) N_packed[(size_t)r + (size_t)c * (c + 1) / 2] = e->hB[(size_t)r * e->Upad + c];
     return JAICOV_OK;
 }
 
@@ -1378,6 +1395,7 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
         }
         hipEventRecord(e1, s);
         const int info = ds.fetch_info();
+        if (info < 0) { status = JAICOV_ERR_DEVICE; break; }
         if (info != 0) { status = JAICOV_ERR_SINGULAR; break; }
         for (int q = 0; q < nrhs; q++) hipMemcpyAsync(b + (size_t)q * n, d_Y + (size_t)q * np, n * sizeof(double), hipMemcpyDeviceToHost, s);
         if (invert) {
@@ -1443,6 +1461,55 @@ extern "C" int jaicov_debug_diag_bench(int dbg, int iters, double *ms_out) {
     hipError_t he = jaicov::diag_kernel_bench(dbg, iters, &ms);
     *ms_out = ms;
     return he == hipSuccess ? 0 : -5;
+}
+
+// Stand-alone timing of the factorisation on a synthetic SPD matrix of order n (multiple of 128): M = R + n I, R uniform in
+// (-0.5, 0.5), right-hand-side rows random.  ms_out[r] = device time of repetition r (HIP events on the solver's stream).
+// trace_out (optional, dataflow factorisation only): [tasks][8] of the LAST repetition, see cholflow.hip; tasks_out = task count.
+__global__ void fill_spd_kernel(double *L, long ld, int n, int nfact) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j > i || i >= n) return;
+    unsigned long long x = 0x9E3779B97F4A7C15ull * ((unsigned long long)i * 65537ull + (unsigned long long)j + 1ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    double v = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    if (i == j && i < nfact) v += (double)nfact;
+    L[(long)i * ld + j] = v;
+}
+extern "C" int jaicov_debug_potrf_bench(int n, int reps, double *ms_out, long long *trace_out, long long trace_cap, int *tasks_out) {
+    std::string err;
+    if (check_device(err)) return JAICOV_ERR_NO_DEVICE;
+    if (n <= 0 || n % 128 || reps < 1 || !ms_out) return JAICOV_ERR_BAD_ARGUMENT;
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return JAICOV_ERR_DEVICE;
+    DenseSolver ds;
+    int status = JAICOV_OK;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    do {
+        if (ds.init(s, n, false, true) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
+        if (trace_out && ds.flow_ready) ds.flow_enable_trace(true);
+        for (int r = 0; r < reps; r++) {
+            hipLaunchKernelGGL(fill_spd_kernel, dim3((ds.n + 255) / 256, ds.n), dim3(256), 0, s, ds.L, ds.ld, ds.n, n);
+            hipEventRecord(e0, s);
+            if (ds.potrf() != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
+            hipEventRecord(e1, s);
+            const int info = ds.fetch_info();
+            if (info != 0) { status = info < 0 ? JAICOV_ERR_DEVICE : JAICOV_ERR_SINGULAR; break; }
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            ms_out[r] = ms;
+        }
+        if (status == JAICOV_OK && trace_out && ds.flow_trace) {
+            const long long cnt = std::min<long long>(trace_cap, (long long)ds.flow_tasks * 8);
+            hipMemcpy(trace_out, ds.flow_trace, (size_t)cnt * sizeof(long long), hipMemcpyDeviceToHost);
+        }
+        if (tasks_out) *tasks_out = ds.flow_ready ? ds.flow_tasks : 0;
+    } while (0);
+    hipStreamSynchronize(s);
+    ds.release();
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipStreamDestroy(s);
+    return status;
 }
 
 // C (M x N row-major) = alpha * op(A) op(B) + beta * C on the device, host buffers in/out (kernel parity + timing)

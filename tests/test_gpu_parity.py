@@ -167,6 +167,34 @@ def test_estimate_lm_and_simulation(oracle_mod):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
+@pytest.mark.parametrize("invert", [engine.INVERT_FULL, engine.INVERT_REDUCED])
+def test_simulation_leaves_parameters_and_gives_the_oracles_cofactors(oracle_mod, name, invert):
+    """EstimationType.SIMULATION (BundleAdjustment.java:830-831): n = 0 for the WHOLE system, so dx = 0 for every unknown --
+    the exterior orientations the engine pre-eliminates (tiny_block) included -- the loop ends after its first two passes,
+    Omega = 0 and Qxx is the cofactor matrix at the start values."""
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    vo, Qo, ro = o.estimate(simulation=True)
+    np.testing.assert_array_equal(vo, fp.values)
+    eng = engine.Engine(fp)
+    v, r = eng.estimate(simulation=True, invert=invert)
+    assert r.state == ro.state == 1 and r.iterations == ro.iterations
+    np.testing.assert_array_equal(v, fp.values)            # bit-exact: nothing moved, EO included
+    assert r.omega == 0.0 and r.max_abs_dx == 0.0
+    U, d = fp.n_unknowns, fp.rank_defect
+    k = eng.cofactor_order()
+    Q = packed_to_full(eng.get_cofactor(), k); Qref = packed_to_full(Qo, U)[:k, :k]
+    sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
+    assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-8
+    # one simulated pass through the step-wise ABI as well: the step is exactly zero
+    eng.set_parameters(fp.values)
+    eng.build(fp.sigma2apriori, 0.0, simulation=True)
+    dx = eng.solve(False)
+    assert np.all(dx[d:] == 0.0)
+    eng.close()
+
+
 def test_sharded_engines_sum_to_full(oracle_mod):
     fp = scene.config("tiny_block")
     s2 = fp.sigma2apriori
