@@ -32,6 +32,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "dense.h"
@@ -65,9 +67,21 @@ struct FlowArgs {
     int *applied;            // [row blocks][fs]  block columns [0, applied) have been subtracted from the stored tile (partial visits)
     int *diag_ready;         // [nb] the updated diagonal tile is in memory
     int *info;               // first failing pivot (dense.h)
+    int *alive;              // host-visible word: the diagonal kernel stores `seq` there when it starts (potrf_flow's handshake)
+    int seq;
+    // optional: the matrix is not in L yet but is M = V N V + Bh' Bh (identity on the d border rows and on the padding) of a
+    // source square N (NES.applyPrecondition, NES:82-91, fused into the first load of every tile; engine.hip scale_copy_kernel)
+    const double *src;       // N, row-major lower, leading dimension src_ld; null = the tiles are in L
+    long src_ld;
+    const double *V;         // [>= 128 nb]
+    const double *Bh;        // [d][bstride]
+    int d, U, bstride;
+    const double *zeros;     // 64 zeros
     double *scratch;         // [grid][128 x 128] per workgroup: operand of the multiplication by inv(L_jj)'
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
-    long long *trace;        // optional [n_tasks][8]: start, C loaded, updates done, end (wall clock), ticks spent waiting, XCC id
+    int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
+    int crit_prio;           // s_setprio level of the tasks on the critical chain (tiles (j,j) and (j+1,j)); 0 = none
+    long long *trace;        // optional [n_tasks][8]: start, C loaded, updates done, end (wall clock), ticks spent waiting, cycles, block, HW_ID | XCC_ID << 32
 };
 
 __device__ __forceinline__ int flow_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -100,69 +114,105 @@ __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+template <int PF>   // PF = k-steps the operand loads run ahead of the MFMAs (1 or 2)
 __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
     __shared__ double smem[2 * FLOW_STAGE];
     __shared__ int s_msg[4];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
-    // operand staging (gemm_f64.h, KC layout: 8 lanes fetch the 16 k of one row, transposed on the way into LDS)
-    const int seg = tid & 7, rbase = tid >> 3;
-    const int odd = (seg & 1) * FLOW_LDS;
-    const int st_lds = (2 * seg) * FLOW_LDS + rbase + 8 * ((seg >> 1) & 1) + 4 * (seg >> 2);
-    const int fa = (lane >> 4) * FLOW_LDS + 64 * wr + (lane & 15);
-    const int fb = (lane >> 4) * FLOW_LDS + 64 * wc + (lane & 15);
-    double *const my_scratch = g.scratch + (long)blockIdx.x * 16384;
+    // Everything derived from the thread index is recomputed where it is used, from a copy of tid the compiler cannot see
+    // through: hoisted out of the persistent loop those values (dozens of them) stay live across the MFMA loop, the kernel
+    // spills, and a kernel with a scratch segment is admitted with fewer waves per shader engine (measured: 458 of the 496
+    // workgroups resident).
+#define FLOW_OPAQUE_TID(name) int name = tid; asm volatile("" : "+v"(name))
 
     d4_t acc[4][4];
-    // acc += A B' over nk k-steps of 16: A(x, k) = Ap[x * lda + k], B(y, k) = Bp[y * ldb + k], x, y < 128
-    auto accumulate = [&](const double *Ap, long lda, const double *Bp, long ldb, int nk) __attribute__((always_inline)) {
+    // acc += asign * A B' over nk k-steps of 16: A(x, k) = Ap[x * lda + k], B(y, k) = Bp[y * ldb + k], x, y < 128.  The sign
+    // rides on the A operand's way into LDS, so that the accumulators always hold the tile itself (never its negative:
+    // a sign applied at load / store time costs a second set of 128 registers around the epilogue).
+    auto accumulate = [&](const double *Ap, long lda, const double *Bp, long ldb, int nk, double asign) __attribute__((always_inline)) {
+        FLOW_OPAQUE_TID(tq);
+        // operand staging (gemm_f64.h, KC layout: 8 lanes fetch the 16 k of one row, transposed on the way into LDS)
+        const int seg = tq & 7, rbase = tq >> 3, lane = tq & 63, wave = tq >> 6;
+        const int odd = (seg & 1) * FLOW_LDS;
+        const int st_lds = (2 * seg) * FLOW_LDS + rbase + 8 * ((seg >> 1) & 1) + 4 * (seg >> 2);
+        const int fa = (lane >> 4) * FLOW_LDS + 64 * (wave >> 1) + (lane & 15);
+        const int fb = (lane >> 4) * FLOW_LDS + 64 * (wave & 1) + (lane & 15);
         const double *ap = Ap + (long)rbase * lda + 2 * seg;
         const double *bp = Bp + (long)rbase * ldb + 2 * seg;
-        d2_t ra[4], rb[4];
-        auto gload = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) ra[q] = *reinterpret_cast<const d2_t *>(ap + (long)(32 * q) * lda);
-#pragma unroll
-            for (int q = 0; q < 4; q++) rb[q] = *reinterpret_cast<const d2_t *>(bp + (long)(32 * q) * ldb);
-            ap += GEMM_BK;
-            bp += GEMM_BK;
-        };
-        auto lstore = [&](int stage) __attribute__((always_inline)) {
-            double *sa = smem + stage * FLOW_STAGE + st_lds;
-            double *sb = sa + GEMM_BK * FLOW_LDS;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                sa[32 * q + odd] = ra[q].x;
-                sa[32 * q + FLOW_LDS - odd] = ra[q].y;
-                sb[32 * q + odd] = rb[q].x;
-                sb[32 * q + FLOW_LDS - odd] = rb[q].y;
-            }
-        };
-        gload();
-        lstore(0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt++) {
-            const int st = kt & 1;
-            if (kt + 1 < nk) gload();
-            const double *sa = smem + st * FLOW_STAGE + fa;
-            const double *sb = smem + st * FLOW_STAGE + GEMM_BK * FLOW_LDS + fb;
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                double a[4], b[4];
-                const int sh = 8 * (ks & 1) + 4 * (ks >> 1);
-#pragma unroll
-                for (int x = 0; x < 4; x++) a[x] = sa[(4 * ks) * FLOW_LDS + 16 * x + sh];
-#pragma unroll
-                for (int y = 0; y < 4; y++) b[y] = sb[(4 * ks) * FLOW_LDS + 16 * y + sh];
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-#pragma unroll
-                    for (int y = 0; y < 4; y++) acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);
-            }
-            if (kt + 1 < nk) lstore(st ^ 1);
+        // Operands travel global -> registers -> LDS, TWO k-steps ahead: the A strips of the tiles of one column are all
+        // different (no reuse in L2 as in gemm_f64.h's super-tiles), they come from HBM, and one k-step (~4 us) of lead did
+        // not always cover that latency with every CU streaming (the left-looking loop ran at 86 % of the matrix pipe).
+        d2_t ra[2][4], rb[2][4];
+#define FLOW_GLOAD(S)                                                                                        \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) ra[S][q] = *reinterpret_cast<const d2_t *>(ap + (long)(32 * q) * lda); \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) rb[S][q] = *reinterpret_cast<const d2_t *>(bp + (long)(32 * q) * ldb); \
+        ++ls;                                                                                                \
+        const long adv = ls < nk ? GEMM_BK : 0;   /* past the last step: the same addresses again, never beyond */ \
+        ap += adv;                                                                                           \
+        bp += adv;                                                                                           \
+    } while (0)
+#define FLOW_LSTORE(S, STAGE)                                                                                \
+    do {                                                                                                     \
+        double *sa = smem + (STAGE) * FLOW_STAGE + st_lds;                                                   \
+        double *sb = sa + GEMM_BK * FLOW_LDS;                                                                \
+        _Pragma("unroll") for (int q = 0; q < 4; q++) {                                                      \
+            sa[32 * q + odd] = asign * ra[S][q].x;                                                           \
+            sa[32 * q + FLOW_LDS - odd] = asign * ra[S][q].y;                                                \
+            sb[32 * q + odd] = rb[S][q].x;                                                                   \
+            sb[32 * q + FLOW_LDS - odd] = rb[S][q].y;                                                        \
+        }                                                                                                    \
+    } while (0)
+#define FLOW_MFMA(STAGE)                                                                                     \
+    do {                                                                                                     \
+        const double *sa = smem + (STAGE) * FLOW_STAGE + fa;                                                 \
+        const double *sb = smem + (STAGE) * FLOW_STAGE + GEMM_BK * FLOW_LDS + fb;                            \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                   \
+            double a[4], b[4];                                                                               \
+            const int sh = 8 * (ks & 1) + 4 * (ks >> 1);                                                     \
+            _Pragma("unroll") for (int x = 0; x < 4; x++) a[x] = sa[(4 * ks) * FLOW_LDS + 16 * x + sh];      \
+            _Pragma("unroll") for (int y = 0; y < 4; y++) b[y] = sb[(4 * ks) * FLOW_LDS + 16 * y + sh];      \
+            _Pragma("unroll") for (int x = 0; x < 4; x++)                                                    \
+                _Pragma("unroll") for (int y = 0; y < 4; y++)                                                \
+                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);        \
+        }                                                                                                    \
+    } while (0)
+        // nk is a multiple of 8.  The loads are issued unconditionally (the last two of a run re-read the last step): behind
+        // a branch the compiler's s_waitcnt placement has to assume the loads were NOT issued and waits for vmcnt(0) before
+        // the LDS stores, i.e. for the loads of two steps ahead as well.
+        int ls = 0;                    // steps whose loads have been issued
+        FLOW_GLOAD(0);                 // step 0
+        if (PF == 2) {
+            FLOW_GLOAD(1);             // step 1
+            FLOW_LSTORE(0, 0);
             __syncthreads();
+            for (int kt = 0; kt < nk; kt += 2) {
+                FLOW_GLOAD(0);         // step kt + 2
+                FLOW_MFMA(0);          // step kt
+                FLOW_LSTORE(1, 1);     // step kt + 1
+                __syncthreads();
+                FLOW_GLOAD(1);         // step kt + 3
+                FLOW_MFMA(1);          // step kt + 1
+                FLOW_LSTORE(0, 0);     // step kt + 2 (after the last step: unused)
+                __syncthreads();
+            }
+        } else {
+            FLOW_LSTORE(0, 0);
+            __syncthreads();
+            for (int kt = 0; kt < nk; kt += 2) {
+                FLOW_GLOAD(0);         // step kt + 1
+                FLOW_MFMA(0);          // step kt
+                FLOW_LSTORE(0, 1);
+                __syncthreads();
+                FLOW_GLOAD(0);         // step kt + 2
+                FLOW_MFMA(1);          // step kt + 1
+                FLOW_LSTORE(0, 0);
+                __syncthreads();
+            }
         }
+#undef FLOW_GLOAD
+#undef FLOW_LSTORE
+#undef FLOW_MFMA
     };
 
     for (;;) {
@@ -174,108 +224,26 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
         const int4 tk = g.tasks[t];
         const int ti = tk.x, tj = tk.y, k0 = tk.z, k1 = tk.w & (FLOW_FIN - 1);
         const bool fin = (tk.w & FLOW_FIN) != 0;
-        long long waited = 0, t_start = 0, t_c = 0, t_upd = 0;
+        long long waited = 0, t_start = 0, t_c = 0, t_upd = 0, c_c = 0, c_upd = 0, w_upd = 0;
+        int n_runs = 0;
         if (g.trace) t_start = wall_clock64();
         bool ok = true;
-        // ---- the tile as it stands ------------------------------------------------------------------------------
-        if (k0 > 0) {   // an earlier (partial) visit wrote it: wait for that visit
-            if (tid == 0) {
-                const bool r = flow_spin(g.applied + (long)ti * g.fs + tj, k0, g.ctrl, g.timeout, &waited);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                drain_stores();
-                s_msg[1] = r ? 1 : 0;
-            }
-            __syncthreads();
-            ok = s_msg[1] != 0;
-            __syncthreads();
-            if (!ok) break;
-        }
-        double *const ctile = g.L + ((long)ti * 128 + 64 * wr + (lane >> 4)) * g.ld + (long)tj * 128 + 64 * wc + (lane & 15);
-#pragma unroll
-        for (int x = 0; x < 4; x++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double *rowp = ctile + (long)(16 * x + 4 * r) * g.ld;
-#pragma unroll
-                for (int y = 0; y < 4; y++) acc[x][y][r] = -rowp[16 * y];
-            }
-        if (g.trace) t_c = wall_clock64();
-        // ---- runs of MFMA work: updates with the block columns whose operand tiles are final, then (off-diagonal tile that is
-        //      to be finished) the multiplication by inv(L_jj)'.  ONE instance of the pipelined loop serves both. ------------
+        // the chain diag(j) -> L[j+1][j] -> tile (j+1,j+1) -> diag(j+1) bounds the whole factorisation whenever the trailing work is
+        // short: its two tile tasks take the matrix pipe ahead of the workgroup they share their SIMDs with
+        const bool critical = fin && ti <= tj + 1 && g.crit_prio > 0;
+        if (critical) __builtin_amdgcn_s_setprio(3);
+        // ---- one or two phases, each: accumulators <- memory, runs of MFMA work, accumulators -> memory.  Phase 0: the tile
+        //      and its updates.  Phase 1 (off-diagonal tile that is to be finished): zeros, then C inv(L_jj)' with C read back
+        //      from this workgroup's scratch tile.  ONE load site, ONE instance of the pipelined loop and ONE store site, and the
+        //      accumulators' live range never crosses a phase: anything else made the compiler shuffle and spill them.
         int k = k0;
-        bool solved = false;          // the accumulators hold L[i][j] (after the multiplication by inv(L_jj)')
-        for (;;) {
-            const double *Ap, *Bp;
-            long lda, ldb;
-            int nk;
-            if (k < k1) {
-                if (wave == 0) {
-                    const int *fi = g.done + (long)ti * g.fs, *fj = g.done + (long)tj * g.fs;
-                    const long long t0 = wall_clock64();
-                    int spins = 0, cnt = 0;
-                    for (;;) {
-                        const int idx = k + lane;
-                        const bool ready = idx < k1 && flow_ld(fi + idx) != 0 && flow_ld(fj + idx) != 0;
-                        const unsigned long long m = __ballot(ready);
-                        cnt = m == ~0ull ? 64 : __builtin_ctzll(~m);
-                        if (cnt > 0) break;
-                        if (++spins < 32) __builtin_amdgcn_s_sleep(4);
-                        else {
-                            __builtin_amdgcn_s_sleep(40);
-                            if ((spins & 31) == 0) {
-                                if (flow_ld(g.ctrl + FLOW_ABORT) != 0) break;
-                                if (wall_clock64() - t0 > g.timeout) { flow_st(g.ctrl + FLOW_ABORT, 2); break; }
-                            }
-                        }
-                    }
-                    if (spins > 0) waited += wall_clock64() - t0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    drain_stores();
-                    if (lane == 0) s_msg[1] = cnt;
-                }
-                __syncthreads();
-                const int cnt = s_msg[1];
-                __syncthreads();
-                if (cnt == 0) { ok = false; break; }
-                Ap = g.L + (long)ti * 128 * g.ld + (long)k * 128;
-                Bp = g.L + (long)tj * 128 * g.ld + (long)k * 128;
-                lda = ldb = g.ld;
-                nk = 8 * cnt;
-                k += cnt;
-            } else {
-                if (g.trace && !solved) t_upd = wall_clock64();
-                // what leaves the accumulators, where to, and which flag tells whom
-                double *dst;
-                long dld;
-                double sign;
-                int *flag;
-                int flag_value = 1;
-                const bool to_scratch = fin && ti != tj && !solved;
-                if (to_scratch) {   // C for the multiplication by inv(L_jj)': through this workgroup's scratch tile
-                    dst = my_scratch + (64 * wr + (lane >> 4)) * 128 + 64 * wc + (lane & 15); dld = 128; sign = -1.0; flag = nullptr;
-                } else if (solved) {   // L[i][j]
-                    dst = ctile; dld = g.ld; sign = 1.0; flag = g.done + (long)ti * g.fs + tj;
-                } else if (fin) {      // updated diagonal tile, for the diagonal kernel
-                    dst = ctile; dld = g.ld; sign = -1.0; flag = g.diag_ready + tj;
-                } else {               // partial visit
-                    dst = ctile; dld = g.ld; sign = -1.0; flag = g.applied + (long)ti * g.fs + tj; flag_value = k1;
-                }
-#pragma unroll
-                for (int x = 0; x < 4; x++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        double *rowp = dst + (long)(16 * x + 4 * r) * dld;
-#pragma unroll
-                        for (int y = 0; y < 4; y++) store_wt(rowp + 16 * y, sign * acc[x][y][r]);
-                    }
-                drain_stores();
-                if (!to_scratch) {
-                    __syncthreads();
-                    if (tid == 0) flow_st(flag, flag_value);
-                    break;
-                }
+        for (int phase = 0;; phase++) {
+            // -- what has to be there before the accumulators are loaded
+            if ((phase == 0 && k0 > 0) || phase == 1) {
                 if (tid == 0) {
-                    const bool r = flow_spin(g.done + (long)tj * g.fs + tj, 1, g.ctrl, g.timeout, &waited);
+                    // phase 0: an earlier (partial) visit wrote the tile; phase 1: inv(L_jj) from the diagonal kernel
+                    const int *f = phase == 0 ? g.applied + (long)ti * g.fs + tj : g.done + (long)tj * g.fs + tj;
+                    const bool r = flow_spin(f, phase == 0 ? k0 : 1, g.ctrl, g.timeout, &waited);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     drain_stores();
                     s_msg[1] = r ? 1 : 0;
@@ -284,24 +252,139 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                 ok = s_msg[1] != 0;
                 __syncthreads();
                 if (!ok) break;
+            }
+            {
+                FLOW_OPAQUE_TID(tq);
+                const long trow = 64 * (tq >> 7) + ((tq & 63) >> 4), tcol = 64 * ((tq >> 6) & 1) + (tq & 15);
+                // phase 1 starts from zeros: read like a tile (row stride 0) so that there is one load site
+                const bool scaled = phase == 0 && k0 == 0 && g.src != nullptr && ti < g.nb;   // first load of a matrix tile from N
+                const double *src = phase != 0 ? g.zeros + (tq & 15)
+                                    : scaled   ? g.src + ((long)ti * 128 + trow) * g.src_ld + (long)tj * 128 + tcol
+                                               : g.L + ((long)ti * 128 + trow) * g.ld + (long)tj * 128 + tcol;
+                const long sld = phase != 0 ? 0 : (scaled ? g.src_ld : g.ld);
 #pragma unroll
                 for (int x = 0; x < 4; x++)
 #pragma unroll
-                    for (int y = 0; y < 4; y++) acc[x][y] = (d4_t){0.0, 0.0, 0.0, 0.0};
-                Ap = my_scratch;
-                Bp = g.invd + (long)tj * 16384;
-                lda = ldb = 128;
-                nk = 8;
-                solved = true;
+                    for (int r = 0; r < 4; r++) {
+                        const double *rowp = src + (long)(16 * x + 4 * r) * sld;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) acc[x][y][r] = rowp[16 * y];
+                    }
+                if (scaled) {
+                    const int R0 = ti * 128 + (int)trow, C0 = tj * 128 + (int)tcol;
+                    double vc[4];
+#pragma unroll
+                    for (int y = 0; y < 4; y++) vc[y] = g.V[C0 + 16 * y];
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int R = R0 + 16 * x + 4 * r;
+                            const double vr = g.V[R];
+#pragma unroll
+                            for (int y = 0; y < 4; y++) {
+                                const int Cc = C0 + 16 * y;
+                                double v = vr * acc[x][y][r] * vc[y];
+                                for (int a = 0; a < g.d; a++) v += g.Bh[(long)a * g.bstride + R] * g.Bh[(long)a * g.bstride + Cc];
+                                const bool inside = R >= g.d && R < g.U && Cc >= g.d;
+                                acc[x][y][r] = inside ? v : (R == Cc ? 1.0 : 0.0);
+                            }
+                        }
+                }
             }
-            accumulate(Ap, lda, Bp, ldb, nk);
+            if (g.trace && phase == 0) { t_c = wall_clock64(); c_c = clock64(); }
+            // -- runs: phase 0: the block columns [k, k1) as their operand tiles become final; phase 1: one run of 8 k-steps
+            for (bool more = true; more;) {
+                const double *Ap, *Bp;
+                long lda, ldb;
+                int nk;
+                double asign;
+                if (phase == 0) {
+                    if (k >= k1) break;
+                    if (tid < 64) {
+                        FLOW_OPAQUE_TID(lane);
+                        const int *fi = g.done + (long)ti * g.fs, *fj = g.done + (long)tj * g.fs;
+                        const long long t0 = wall_clock64();
+                        int spins = 0, cnt = 0;
+                        for (;;) {
+                            const int idx = k + lane;
+                            const bool ready = idx < k1 && flow_ld(fi + idx) != 0 && flow_ld(fj + idx) != 0;
+                            const unsigned long long m = __ballot(ready);
+                            cnt = m == ~0ull ? 64 : __builtin_ctzll(~m);
+                            if (cnt > 0) break;
+                            if (++spins < 32) __builtin_amdgcn_s_sleep(4);
+                            else {
+                                __builtin_amdgcn_s_sleep(40);
+                                if ((spins & 31) == 0) {
+                                    if (flow_ld(g.ctrl + FLOW_ABORT) != 0) break;
+                                    if (wall_clock64() - t0 > g.timeout) { flow_st(g.ctrl + FLOW_ABORT, 2); break; }
+                                }
+                            }
+                        }
+                        if (spins > 0) waited += wall_clock64() - t0;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        drain_stores();
+                        if (lane == 0) s_msg[1] = cnt;
+                    }
+                    __syncthreads();
+                    const int cnt = s_msg[1];
+                    __syncthreads();
+                    if (cnt == 0) { ok = false; break; }
+                    ++n_runs;
+                    Ap = g.L + (long)(g.fake_a ? tj : ti) * 128 * g.ld + (long)k * 128;
+                    Bp = g.L + (long)tj * 128 * g.ld + (long)k * 128;
+                    lda = ldb = g.ld;
+                    nk = 8 * cnt;
+                    asign = -1.0;             // C -= L[i][k] L[j][k]'
+                    k += cnt;
+                } else {
+                    Ap = g.scratch + (long)blockIdx.x * 16384;
+                    Bp = g.invd + (long)tj * 16384;
+                    lda = ldb = 128;
+                    nk = 8;
+                    asign = 1.0;              // L[i][j] = C inv(L_jj)'
+                    more = false;
+                }
+                accumulate(Ap, lda, Bp, ldb, nk, asign);
+            }
+            if (!ok) break;
+            if (g.trace && phase == 0) { t_upd = wall_clock64(); c_upd = clock64(); w_upd = waited; }
+            // -- where the accumulators go, and which flag tells whom
+            const bool to_scratch = phase == 0 && fin && ti != tj;
+            {
+                FLOW_OPAQUE_TID(tq);
+                const long trow = 64 * (tq >> 7) + ((tq & 63) >> 4), tcol = 64 * ((tq >> 6) & 1) + (tq & 15);
+                double *dst = to_scratch ? g.scratch + (long)blockIdx.x * 16384 + trow * 128 + tcol
+                                         : g.L + ((long)ti * 128 + trow) * g.ld + (long)tj * 128 + tcol;
+                const long dld = to_scratch ? 128 : g.ld;
+#pragma unroll
+                for (int x = 0; x < 4; x++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        double *rowp = dst + (long)(16 * x + 4 * r) * dld;
+#pragma unroll
+                        for (int y = 0; y < 4; y++) store_wt(rowp + 16 * y, acc[x][y][r]);
+                    }
+            }
+            drain_stores();
+            if (to_scratch) continue;     // phase 1 follows (its wait comes with a barrier)
+            __syncthreads();
+            if (tid == 0) {
+                if (phase == 1) flow_st(g.done + (long)ti * g.fs + tj, 1);                 // L[i][j] is final
+                else if (fin) flow_st(g.diag_ready + tj, 1);                               // updated diagonal tile, for the diagonal kernel
+                else flow_st(g.applied + (long)ti * g.fs + tj, k1);                        // partial visit
+            }
+            break;
         }
+        if (critical) __builtin_amdgcn_s_setprio(0);
         if (!ok) break;
         if (g.trace && tid == 0) {
             long long *tr = g.trace + 8 * (long)t;
             tr[0] = t_start; tr[1] = t_c; tr[2] = t_upd; tr[3] = wall_clock64(); tr[4] = waited;
-            tr[5] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf;   // XCC_ID
-            tr[6] = blockIdx.x;
+            tr[5] = c_upd - c_c;   // shader-clock cycles of the update phase (against tr[2] - tr[1] at 100 MHz: the clock it ran at)
+            tr[6] = (long long)blockIdx.x | ((long long)n_runs << 16) | (w_upd << 32);   // block, runs, ticks waited before the updates were done
+            tr[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |                              // HW_ID
+                    ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) << 32);   // XCC_ID
         }
     }
 }
@@ -312,6 +395,7 @@ __global__ __launch_bounds__(256) void potrf_diag_chain_kernel(FlowArgs g) {
     __shared__ double Wd[8 * 16 * WDP];
     __shared__ int s_ok;
     const int tid = threadIdx.x;
+    if (tid == 0 && g.alive) __hip_atomic_store(g.alive, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // resident: the tile kernel may come
     for (int c = 0; c < g.nb; c++) {
         if (tid == 0) {
             const bool r = flow_spin(g.diag_ready + c, 1, g.ctrl, g.timeout, nullptr);
@@ -336,20 +420,29 @@ __global__ __launch_bounds__(256) void potrf_diag_chain_kernel(FlowArgs g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Task list: left-looking, column-major.  Column j: the diagonal tile first, then the tiles below it (the tile right below
-// feeds the next diagonal tile: it is the one the chain waits for), the right-hand-side rows last.
-static std::vector<int4> flow_schedule(int nb, int row_blocks) {
+// Task list: left-looking.  w = 1: column-major; column j: the diagonal tile first, then the tiles below it (the tile right
+// below feeds the next diagonal tile: it is the one the chain waits for), the right-hand-side rows last.  w > 1: groups of w
+// columns; the tiles of the group's diagonal blocks first, then row by row the w tiles of a row, which stream the same A
+// strip L[i][0..j) at the same time (the second reader finds it in L2 / the Infinity Cache).  Either way a tile only depends
+// on tiles that come earlier in the list.
+static std::vector<int4> flow_schedule(int nb, int row_blocks, int w) {
     std::vector<int4> tasks;
     tasks.reserve((size_t)nb * (row_blocks + 1) / 2 + row_blocks);
-    for (int j = 0; j < nb; j++)
-        for (int i = j; i < row_blocks; i++) tasks.push_back(make_int4(i, j, 0, j | FLOW_FIN));
+    if (w < 1) w = 1;
+    for (int j0 = 0; j0 < nb; j0 += w) {
+        const int j1 = std::min(nb, j0 + w);
+        for (int j = j0; j < j1; j++)
+            for (int i = j; i < j1; i++) tasks.push_back(make_int4(i, j, 0, j | FLOW_FIN));
+        for (int i = j1; i < row_blocks; i++)
+            for (int j = j0; j < j1; j++) tasks.push_back(make_int4(i, j, 0, j | FLOW_FIN));
+    }
     return tasks;
 }
 
 hipError_t DenseSolver::flow_init() {
     const int nb = nfact / 128, row_blocks = n / 128;
-    if (!ustream || !dstream) return hipErrorNotSupported;
-    const std::vector<int4> tasks = flow_schedule(nb, row_blocks);
+    if (!dstream) return hipErrorNotSupported;
+    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1);
     flow_tasks = (int)tasks.size();
     HIPCHK(hipMalloc(&flow_task_list, tasks.size() * sizeof(int4)));
     HIPCHK(hipMemcpy(flow_task_list, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
@@ -361,13 +454,17 @@ hipError_t DenseSolver::flow_init() {
     hipDeviceProp_t prop;
     int dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    flow_grid = 2 * (cus - 8);       // two workgroups per CU of the update stream's mask (dense.hip: CU 31 of every XCD is reserved)
+    flow_grid = 2 * cus;             // two workgroups per CU; the CU of the diagonal kernel takes none, the surplus stays queued (harmless)
     if (const char *e = getenv("JAICOV_FLOW_GRID")) flow_grid = atoi(e);
     if (flow_grid < 1) flow_grid = 1;
-    HIPCHK(hipMalloc(&flow_scratch, (size_t)flow_grid * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&flow_scratch, ((size_t)flow_grid * 16384 + 64) * sizeof(double)));
+    HIPCHK(hipMemset(flow_scratch + (size_t)flow_grid * 16384, 0, 64 * sizeof(double)));
+    HIPCHK(hipHostMalloc((void **)&flow_alive, sizeof(int), hipHostMallocMapped));
+    *flow_alive = 0;
     HIPCHK(hipEventCreateWithFlags(&flow_e0, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e1, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e2, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&flow_e3, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&flow_t0));
     HIPCHK(hipEventCreate(&flow_t1));
     flow_ready = true;
@@ -379,10 +476,12 @@ void DenseSolver::flow_release() {
     if (flow_flags) hipFree(flow_flags);
     if (flow_scratch) hipFree(flow_scratch);
     if (flow_trace) hipFree(flow_trace);
-    for (hipEvent_t e : {flow_e0, flow_e1, flow_e2, flow_t0, flow_t1})
+    if (flow_alive) hipHostFree(flow_alive);
+    flow_alive = nullptr;
+    for (hipEvent_t e : {flow_e0, flow_e1, flow_e2, flow_e3, flow_t0, flow_t1})
         if (e) hipEventDestroy(e);
     flow_task_list = nullptr; flow_flags = nullptr; flow_scratch = nullptr; flow_trace = nullptr;
-    flow_e0 = flow_e1 = flow_e2 = flow_t0 = flow_t1 = nullptr;
+    flow_e0 = flow_e1 = flow_e2 = flow_e3 = flow_t0 = flow_t1 = nullptr;
     flow_ready = false;
 }
 
@@ -397,28 +496,46 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.diag_ready = g.applied + (size_t)row_blocks * nb;
     g.info = d_info;
     g.scratch = flow_scratch;
+    g.zeros = flow_scratch + (size_t)flow_grid * 16384;
     g.timeout = 100000000LL * (getenv("JAICOV_FLOW_TIMEOUT_S") ? atoi(getenv("JAICOV_FLOW_TIMEOUT_S")) : 10);
+    g.src = flow_src; g.src_ld = flow_src_ld; g.V = flow_V; g.Bh = flow_Bh; g.d = flow_d; g.U = flow_U; g.bstride = flow_bstride;
+    flow_src = nullptr;      // one factorisation only
     g.trace = flow_trace;
+    g.fake_a = getenv("JAICOV_FLOW_FAKE_A") ? atoi(getenv("JAICOV_FLOW_FAKE_A")) : 0;
+    g.crit_prio = getenv("JAICOV_FLOW_PRIO") ? atoi(getenv("JAICOV_FLOW_PRIO")) : 1;
+    g.alive = flow_alive;
+    g.seq = ++flow_seq;
     HIPCHK(hipMemsetAsync(flow_flags, 0, flow_words * sizeof(int), stream));
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
     HIPCHK(hipEventRecord(flow_e0, stream));
     HIPCHK(hipStreamWaitEvent(dstream, flow_e0, 0));
-    HIPCHK(hipStreamWaitEvent(ustream, flow_e0, 0));
-    if (all_ready) {
-        HIPCHK(hipStreamWaitEvent(dstream, all_ready, 0));
-        HIPCHK(hipStreamWaitEvent(ustream, all_ready, 0));
-    }
+    if (all_ready) HIPCHK(hipStreamWaitEvent(dstream, all_ready, 0));
     hipLaunchKernelGGL(potrf_diag_chain_kernel, dim3(1), dim3(256), 0, dstream, g);
-    if (profile) HIPCHK(hipEventRecord(flow_t0, ustream));
-    hipLaunchKernelGGL(chol_tile_kernel, dim3(flow_grid), dim3(256), 0, ustream, g);
+    HIPCHK(hipGetLastError());
+    // Residency.  The diagonal kernel needs a whole CU's LDS and runs on the stream whose CU mask holds one CU of every XCD.
+    // The tile kernel runs on the ORDINARY stream with all CUs: on a stream masked to the other 248 CUs only 458 of 496
+    // workgroups became resident (measured: workgroups are dealt round-robin to the four shader engines of an XCD, the engine
+    // that holds the reserved CU takes 14, and the first workgroup that does not fit holds back the rest of that XCD's queue);
+    // unmasked, every CU takes two.  So that the tile kernel cannot fill the reserved CUs before the diagonal kernel has one,
+    // the host launches it only after the diagonal kernel has said that it is running (one word of host-visible memory).
+    {
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq) {
+            if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
+                return hipErrorLaunchTimeOut;
+        }
+    }
+    if (profile) HIPCHK(hipEventRecord(flow_t0, stream));
+    static const int pf = getenv("JAICOV_FLOW_PF") ? atoi(getenv("JAICOV_FLOW_PF")) : 1;   // measured equal (22.7-23.0 ms at order 15104): one step of lead covers the latency
+    if (pf == 1) hipLaunchKernelGGL(chol_tile_kernel<1>, dim3(flow_grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(chol_tile_kernel<2>, dim3(flow_grid), dim3(256), 0, stream, g);
     if (profile) {
-        HIPCHK(hipEventRecord(flow_t1, ustream));
+        HIPCHK(hipEventRecord(flow_t1, stream));
         flow_timed = true;
     }
     HIPCHK(hipEventRecord(flow_e1, dstream));
-    HIPCHK(hipEventRecord(flow_e2, ustream));
     HIPCHK(hipStreamWaitEvent(stream, flow_e1, 0));
-    HIPCHK(hipStreamWaitEvent(stream, flow_e2, 0));
     return hipGetLastError();
 }
 

@@ -28,6 +28,7 @@ struct DenseSolver {
     hipStream_t pstream = nullptr;   // panel GEMMs (high priority)
     hipStream_t ustream = nullptr;   // trailing updates: all CUs except the reserved ones (CU mask)
     hipStream_t dstream = nullptr;   // diagonal-block kernel: the reserved CUs
+    hipStream_t ustream2 = nullptr;  // second stream with the update mask (dataflow factorisation: second half of the tile kernel's workgroups)
     std::vector<hipEvent_t> sync_ev;
     size_t ev_used = 0;
     hipEvent_t next_event();
@@ -51,13 +52,23 @@ struct DenseSolver {
 
     // dataflow factorisation (cholflow.hip): the whole potrf as two concurrent launches, dependencies as flags in memory
     bool flow_ready = false, flow_timed = false;
+    int reserved_cus = 8;                // CUs kept free of the update stream for the diagonal-block kernel
     int4 *flow_task_list = nullptr;
     int flow_tasks = 0, flow_fs = 0, flow_grid = 0;
     int *flow_flags = nullptr;           // control words, done / applied flags, diag_ready
     size_t flow_words = 0;
     double *flow_scratch = nullptr;
     long long *flow_trace = nullptr;
-    hipEvent_t flow_e0 = nullptr, flow_e1 = nullptr, flow_e2 = nullptr, flow_t0 = nullptr, flow_t1 = nullptr;
+    int *flow_alive = nullptr;           // host-visible: sequence number of the last diagonal kernel that has started
+    int flow_seq = 0;
+    hipEvent_t flow_e0 = nullptr, flow_e1 = nullptr, flow_e2 = nullptr, flow_e3 = nullptr, flow_t0 = nullptr, flow_t1 = nullptr;
+    // source of the NEXT potrf(): M = V N V + Bh' Bh read straight from N by the tile kernel (no scaled copy into L first)
+    const double *flow_src = nullptr, *flow_V = nullptr, *flow_Bh = nullptr;
+    long flow_src_ld = 0;
+    int flow_d = 0, flow_U = 0, flow_bstride = 0;
+    void flow_set_source(const double *N, long ldN, const double *V, const double *Bh, int bstride, int d, int U) {
+        flow_src = N; flow_src_ld = ldN; flow_V = V; flow_Bh = Bh; flow_bstride = bstride; flow_d = d; flow_U = U;
+    }
     hipError_t flow_init();
     void flow_release();
     hipError_t potrf_flow(hipEvent_t all_ready);

@@ -204,7 +204,10 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         if ((nfact >= 2048 || !legacy) && !getenv("JAICOV_NO_CUMASK")) {
             uint32_t upd[8], dia[8];
             for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
-            upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u;
+            // reserved: CU 31 of every XCD (8 CUs, what the stream-scheduled factorisation was tuned with), or of XCD 7 only
+            reserved_cus = getenv("JAICOV_RESERVED_CUS") ? atoi(getenv("JAICOV_RESERVED_CUS")) : 8;
+            if (reserved_cus == 1) { upd[7] = 0x7FFFFFFFu; dia[7] = 0x80000000u; }
+            else { reserved_cus = 8; upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u; }
             if (hipExtStreamCreateWithCUMask(&ustream, 8, upd) != hipSuccess) ustream = nullptr;
             if (hipExtStreamCreateWithCUMask(&dstream, 8, dia) != hipSuccess) dstream = nullptr;
             if (!ustream || !dstream) {
@@ -233,7 +236,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
     }
-    if (!getenv("JAICOV_POTRF_LEGACY") && ustream && dstream) {
+    if (!getenv("JAICOV_POTRF_LEGACY") && dstream) {
         hipError_t fe = flow_init();
         if (fe != hipSuccess) { flow_release(); (void)hipGetLastError(); }   // the stream-scheduled factorisation remains
     }
@@ -254,7 +257,8 @@ void DenseSolver::release() {
     if (pstream) hipStreamDestroy(pstream);
     if (ustream) hipStreamDestroy(ustream);
     if (dstream) hipStreamDestroy(dstream);
-    pstream = ustream = dstream = nullptr;
+    if (ustream2) hipStreamDestroy(ustream2);
+    pstream = ustream = dstream = ustream2 = nullptr;
     L = invd = W = Q = nullptr;
     d_info = nullptr;
     owns = false;

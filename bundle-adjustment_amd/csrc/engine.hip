@@ -996,24 +996,28 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     if (d > 0) HIPE(e, hipMemcpyAsync(e->d_B, Bh.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
     HIPE(e, hipEventRecord(e->ev[4], e->stream));
-    // The columns of the first panel go first, together with the right-hand sides; the panel then factors on its stream
-    // while the rest of the matrix is still being scaled and copied (0.4 ms at config 4).
-    const int c1 = std::min(slv.first_panel_cols(), Up);
-    hipLaunchKernelGGL(scale_copy_kernel, dim3((c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
-                       Up, d, e->d_V, e->d_B, Upad, 0, c1);
     // right-hand sides: row 0 = V n, rows 1..d = Bh.  They are the extra rows below the matrix, so the factorisation
     // itself carries out the forward substitution (dense.hip).
     const int vs = Up;   // stride between the solution vectors (the solver's order)
+    const bool fused = slv.flow_ready && !getenv("JAICOV_NO_FUSED_SCALE");
+    const int c1 = std::min(slv.first_panel_cols(), Up);
+    // dataflow factorisation: the tile kernel reads N itself and scales on the fly (no copy of the matrix at all);
+    // stream-scheduled one: the columns of the first panel go first, together with the right-hand sides; the panel then
+    // factors on its stream while the rest of the matrix is still being scaled and copied (0.4 ms at config 4).
+    if (!fused)
+        hipLaunchKernelGGL(scale_copy_kernel, dim3((c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
+                           Up, d, e->d_V, e->d_B, Upad, 0, c1);
     HIPE(e, hipMemsetAsync(slv.rhs_row(0), 0, (size_t)128 * ld * sizeof(double), e->stream));
     hipLaunchKernelGGL(scale_vec_kernel, dim3((Up + 255) / 256), dim3(256), 0, e->stream, e->d_n, e->d_V, slv.rhs_row(0), U, Up, d);
     if (d > 0)
         HIPE(e, hipMemcpy2DAsync(slv.rhs_row(1), (size_t)ld * sizeof(double), e->d_B, (size_t)Upad * sizeof(double),
                                  (size_t)Up * sizeof(double), (size_t)d, hipMemcpyDeviceToDevice, e->stream));
     HIPE(e, hipEventRecord(e->ev_first, e->stream));
-    if (c1 < Up)
+    if (!fused && c1 < Up)
         hipLaunchKernelGGL(scale_copy_kernel, dim3((Up - c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L,
                            ld, U, Up, d, e->d_V, e->d_B, Upad, c1, Up);
     HIPE(e, hipEventRecord(e->ev_all, e->stream));
+    if (fused) slv.flow_set_source(e->d_N, (long)Upad, e->d_V, e->d_B, Upad, d, U);
     HIPE(e, slv.potrf(e->ev_first, e->ev_all));
     HIPE(e, hipEventRecord(e->ev[5], e->stream));
     HIPE(e, slv.backsolve_aug(e->d_G, vs, nrhs));           // G <- L^-T (L^-1 Y)   (row 0: y~, rows 1..d: G^)
@@ -1491,13 +1495,16 @@ extern "C" int jaicov_debug_potrf_bench(int n, int reps, double *ms_out, long lo
         for (int r = 0; r < reps; r++) {
             hipLaunchKernelGGL(fill_spd_kernel, dim3((ds.n + 255) / 256, ds.n), dim3(256), 0, s, ds.L, ds.ld, ds.n, n);
             hipEventRecord(e0, s);
-            if (ds.potrf() != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
+            const hipError_t pe = ds.potrf();
+            if (pe != hipSuccess) { fprintf(stderr, "potrf: %s\n", hipGetErrorString(pe)); status = JAICOV_ERR_DEVICE; break; }
             hipEventRecord(e1, s);
             const int info = ds.fetch_info();
-            if (info != 0) { status = info < 0 ? JAICOV_ERR_DEVICE : JAICOV_ERR_SINGULAR; break; }
+            if (info < 0) fprintf(stderr, "potrf: info %d (flow_ready %d)\n", info, (int)ds.flow_ready);
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
             ms_out[r] = ms;
+            if (info < 0) { status = JAICOV_ERR_DEVICE; break; }
+            if (info != 0 && !getenv("JAICOV_FLOW_FAKE_A")) { status = JAICOV_ERR_SINGULAR; break; }
         }
         if (status == JAICOV_OK && trace_out && ds.flow_trace) {
             const long long cnt = std::min<long long>(trace_cap, (long long)ds.flow_tasks * 8);

@@ -29,7 +29,7 @@ if want_trace and nt.value:
     wait = t[:, 4] / 100.0
     span = us[:, 3].max()
     busy = (us[:, 3] - us[:, 0]).sum()
-    slots = len(np.unique(t[:, 6]))
+    slots = len(np.unique(t[:, 6] & 0xffff))
     print(f"span {span:.0f} us, workgroups seen {slots}, sum of task time {busy / slots:.0f} us per workgroup, of which waiting {wait.sum() / slots:.0f} us")
     # tasks are column-major: find the diagonal tasks = first task of each column
     idx = 0
@@ -46,5 +46,56 @@ if want_trace and nt.value:
     act = [(np.minimum(us[:, 3], b) - np.maximum(us[:, 0], a)).clip(0).sum() / (b - a) for a, b in zip(q[:-1], q[1:])]
     wt = []
     print("mean resident tasks per tenth of the span:", np.round(act, 0))
+    # which CUs ran the workgroups (HW_ID: cu 11:8, sh 12, se 15:13; XCC id separately)
+    hw = t[:, 7] & 0xffffffff; xcc = (t[:, 7] >> 32) & 0xf; key = xcc * 1000 + ((hw >> 13) & 7) * 100 + ((hw >> 12) & 1) * 10 + ((hw >> 8) & 0xf)
+    wg_cu = {}
+    runs = (t[:, 6] >> 16) & 0xffff; w_upd = (t[:, 6] >> 32) / 100.0
+    for b, k in zip(t[:, 6] & 0xffff, key):
+        wg_cu[int(b)] = int(k)
+    cus = np.unique(list(wg_cu.values()), return_counts=True)
+    print(f"distinct CUs {len(cus[0])}; workgroups per CU histogram {dict(zip(*np.unique(cus[1], return_counts=True)))}; per XCC {np.bincount(np.array(list(wg_cu.values())) // 1000, minlength=8)}")
+    per = {}
+    for k, c in zip(*cus):
+        per.setdefault(int(k) // 1000, []).append(int(c))
+    print("per XCC: CUs / CUs with one workgroup / by shader engine (se*2+sh: CUs, workgroups):")
+    for x in sorted(per):
+        ses = {}
+        for k, c in zip(*cus):
+            if int(k) // 1000 == x:
+                e = (int(k) % 1000) // 10
+                ses.setdefault(e, [0, 0]); ses[e][0] += 1; ses[e][1] += int(c)
+        print(f"  xcc {x}: {len(per[x])} CUs, {per[x].count(1)} single; " + " ".join(f"{e}:{v[0]}/{v[1]}" for e, v in sorted(ses.items())))
+    steps = np.array([nb + 1 - 0] * 0)
+    upd_us = (t[:, 2] - t[:, 1]) / 100.0
+    mhz = t[:, 5] / np.maximum(t[:, 2] - t[:, 1], 1) * 100.0
+    sel = upd_us > 200
+    print(f"shader clock in the update phase (tasks > 200 us): mean {mhz[sel].mean():.0f} MHz p10 {np.percentile(mhz[sel], 10):.0f} p90 {np.percentile(mhz[sel], 90):.0f}")
+    if os.environ.get("JAICOV_FLOW_W", "1") == "1":
+        ks = np.concatenate([np.full(nb + 1 - j, j) for j in range(nb)])
+        mid = (ks > 40) & (ks < 80)
+        fin_us = us[:, 3] - us[:, 2]
+        rowi = np.concatenate([np.arange(j, nb + 1) for j in range(nb)])
+        offd = mid & (rowi != ks)
+        print(f"tiles of columns 41-79: waiting {wait[offd].mean():.0f} us per task, after the updates {fin_us[offd].mean():.0f} us; "
+              f"diagonal tiles: start -> handed over {(us[:, 3] - us[:, 0])[mid & (rowi == ks)].mean():.0f} us vs off-diagonal start -> updates done {(us[:, 2] - us[:, 0])[offd].mean():.0f} us")
+        # how far behind its column's diagonal tile does a tile start / end its updates?
+        starts = np.cumsum([0] + [nb + 1 - j for j in range(nb)])
+        lag_s = np.concatenate([us[starts[j]:starts[j + 1], 0] - us[starts[j], 0] for j in range(nb)])
+        dready = np.concatenate([np.full(nb + 1 - j, us[starts[j], 3]) for j in range(nb)])
+        print(f"   start lag behind the diagonal tile: mean {lag_s[offd].mean():.0f} us, max {lag_s[offd].max():.0f}; updates done relative to diagonal tile handed over: mean {(us[:, 2] - dready)[offd].mean():.0f} us, p10 {np.percentile((us[:, 2] - dready)[offd], 10):.0f}, p90 {np.percentile((us[:, 2] - dready)[offd], 90):.0f}")
+        print(f"   runs per task {runs[offd].mean():.1f} (max {runs[offd].max()}), waiting during the updates {w_upd[offd].mean():.0f} us, waiting for inv(L_jj) {(wait - w_upd)[offd].mean():.0f} us")
+        d_ij = (rowi - ks)
+        for lo, hi in ((1, 2), (2, 8), (8, 30), (30, 200)):
+            m2 = offd & (d_ij >= lo) & (d_ij < hi)
+            if m2.any():
+                print(f"   rows j+{lo}..j+{hi - 1}: waiting during updates {w_upd[m2].mean():.0f} us, runs {runs[m2].mean():.1f}, start lag {lag_s[m2].mean():.0f} us")
+        print(f"update phase per block column, tiles of columns 41-79: {(upd_us[mid] / ks[mid]).mean():.2f} us incl. waits ({(wait[mid] / ks[mid]).mean():.2f} us waiting)")
+        # chain: (j,j) handed to the diagonal kernel -> L[j+1][j] final -> (j+1,j+1) handed over
+        starts = np.cumsum([0] + [nb + 1 - j for j in range(nb)])
+        a = np.array([us[starts[j], 3] for j in range(nb - 1)])
+        b = np.array([us[starts[j] + 1, 3] for j in range(nb - 1)])
+        c = np.array([us[starts[j + 1], 3] for j in range(nb - 1)])
+        for name, sl in (("columns 1-15", slice(1, 16)), ("middle 16", slice(nb // 2 - 8, nb // 2 + 8)), ("last 16", slice(nb - 18, nb - 2))):
+            print(f"chain {name}: diag kernel + solve of L[j+1][j] {np.mean((b - a)[sl]):.1f} us, last update + store of (j+1,j+1) {np.mean((c - b)[sl]):.1f} us")
     pro = us[:, 1] - us[:, 0]
     print(f"C-tile load: mean {pro.mean():.1f} us p90 {np.percentile(pro, 90):.1f};  finish (after updates): mean {(us[:, 3] - us[:, 2]).mean():.1f} us")
