@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- LM iterations/s of the MI355X normal-equation engine on the BASELINE.json headline scene.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one rank per GPU.  Either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+        (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or started plainly: bench.py then starts the N ranks itself
+        (torch.distributed.run as a child process, before anything touches a GPU) and exits with their status.
 
 A "step" is one intermediate Gauss-Newton/LM pass of BundleAdjustment.estimateModel (BundleAdjustment.java:228-355):
 residual + Jacobian rows, N = A'PA / n = A'Pw, datum/damping/preconditioner, factorisation + substitution, parameter
@@ -86,18 +89,67 @@ def cpu_baseline(fp, eng, sigma2):
     t_fac = t_fac_s * (U / ns) ** 3
     sample.append(f"packed dsptrf of the leading {ns}x{ns} block ({t_fac_s:.1f} s) extrapolated by (U/{ns})^3")
     total = t_asm + t_fac
-    return {"value": 1.0 / total, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": "; ".join(sample) + f"; estimated pass = {t_asm:.0f} s assembly + {t_fac:.0f} s factorisation"}
+    res = {"value": 1.0 / total, "unit": "iterations/s", "cores": 1, "kind": "port", "host_nproc": os.cpu_count(), "host_cpu": _cpu_model(),
+           "sample": "; ".join(sample) + f"; estimated pass = {t_asm:.0f} s assembly + {t_fac:.0f} s factorisation"}
+    # the same single-threaded port run ONCE in full at this config (tests/golden/make_cfg4_golden.py, in the build container):
+    # measured, not extrapolated -- quoted beside the live sample so that the extrapolation can be judged
+    meas = os.path.join(ROOT, "tests", "golden", "cfg4", "cfg4_oracle.json")
+    if fp.n_unknowns == 18014 and os.path.exists(meas):
+        try:
+            m = json.load(open(meas))
+            sec = m["seconds"]
+            res["measured_full_pass"] = {"kind": "port, measured", "cores": 1, "intermediate_pass_s": sec["pass1_total"],
+                                         "final_pass_with_inverse_s": sec["pass2_total"], "stages_s": sec["pass1"],
+                                         "final_pass_stages_s": sec["pass2"], "host": m["host"],
+                                         "iterations_per_s": 1.0 / sec["pass1_total"]}
+        except Exception:
+            pass
+    return res
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def spawn_ranks(a):
+    """--gpus N > 1 without a launcher: start N ranks (one per GPU) as a child job and return its exit code.  Nothing in
+    this process has touched a GPU yet (torch.cuda.device_count() does not initialise one on this stack)."""
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} visible GPUs, this node shows {have}: refusing to print an N = 1 line "
+              f"for an N = {a.gpus} request", file=sys.stderr)
+        return 2
+    port = int(os.environ.get("MASTER_PORT", "0")) or 29500 + os.getpid() % 400
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={world} ranks: the two must agree")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants GPU {local}, this node shows {torch.cuda.device_count()}")
     torch.cuda.set_device(local)
     dist = None
     use_dist = world > 1 or bool(os.environ.get("JAICOV_BENCH_FORCE_DIST"))   # the env var rehearses the collective path on 1 GPU
@@ -175,9 +227,13 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.config}: {fp.n_images} images x {fp.n_points} points, {fp.n_image_points} image points, "
                                    f"{fp.n_image_blocks} dense per-image dispersion blocks, U={U}, d={fp.rank_defect}",
-                       "parallelism": f"images sharded over {world} rank(s), packed N all-reduced, replicated solve"},
+                       "parallelism": f"images sharded over {world} rank(s), packed N all-reduced, replicated solve",
+                       "rccl_ranks": (dist.get_world_size() if use_dist else 0)},
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items()},
-            "roofline": {"kernel": "gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update, fp64 MFMA 16x16x4; symbol as listed by rocprofv3)",
+            "roofline": {"kernel": ("gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update of the stream-scheduled factorisation, fp64 MFMA 16x16x4)"
+                                    if os.environ.get("JAICOV_POTRF_LEGACY") else
+                                    "chol_tile_kernel<1> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
+                                    "persistent launch, fp64 MFMA 16x16x4; algorithmic flops = order^3 / 3; symbol as listed by rocprofv3)"),
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": ks["launches"], "avg_launch_ms": ks["ms"] / max(ks["launches"], 1),
@@ -211,10 +267,19 @@ def main():
             out["roofline"]["peak_measured"] = {"constant_operands": meas[0], "random_operands": meas[1], "unit": "TFLOP/s"}
         except Exception:
             pass
+        # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need a pass each and cannot be collected
+        # inside this run): scripts/round_profile.sh regenerates profiles/pmc_traffic.json; the line says which file it quotes.
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
-                out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                import hashlib
+                raw = open(pmc, "rb").read()
+                rec = json.loads(raw)
+                stale = rec.get("kernel", "").split(" ")[0].split("<")[0] not in out["roofline"]["kernel"]
+                out["roofline"]["traffic"] = None if stale else rec.get("hbm_bytes_per_launch")
+                out["roofline"]["traffic_source"] = {"file": "profiles/pmc_traffic.json", "sha1": hashlib.sha1(raw).hexdigest()[:12],
+                                                     "collected": rec.get("collected"), "kernel": rec.get("kernel"),
+                                                     "stale_for_this_kernel": stale}
             except Exception:
                 pass
     if not a.iterations_only:

@@ -355,14 +355,22 @@ __global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t
 // so the strip is updated with LDS atomics (ds_add_f64) and the waves never wait for each other; every wave keeps
 // record and range of its image after next and the operands of its next image in flight while it accumulates.
 // The strip is added to N once at the end: every entry of the point-point block has exactly one owner workgroup.
+// FUSED = the EO pre-elimination's rank-6 downdate applied on the fly: the weights are P' = sigma2 Dinv - U U' (schur.hip)
+// and the 2 x 2 block P'_pq is formed in registers from the streamed Dinv_pq and the rows U_p (wave-uniform) and U_q (12 more
+// doubles per partner, from the 32 MB U buffer that stays in L2 / the Infinity Cache).  P' is then never written to or read
+// from HBM (2 x 2 GB per pass at config 4, and the 4 GB buffer), and D^-1 is read once here instead of once more in a kernel
+// of its own.
+template <bool FUSED>
 struct PPData {           // what one thread needs of one partner point q
     d2_t P0, P1;
     double aq[6];
     int cq[3];
+    d2_t uq[FUSED ? 6 : 1];   // rows 2q, 2q+1 of U (6 values each)
 };
 
-__device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PPRecord &r,
-                                        const int32_t *__restrict__ ipcol, const double *__restrict__ rowsA, int q, int qend) {
+template <bool FUSED>
+__device__ __forceinline__ void pp_load(PPData<FUSED> &d, const DevProblem &p, const PPRecord &r, const int32_t *__restrict__ ipcol,
+                                        const double *__restrict__ rowsA, const double *__restrict__ Ubuf, int q, int qend) {
     const long S = p.n_ip;
     if (q < qend) {
         const int m = 2 * r.mp;
@@ -375,38 +383,94 @@ __device__ __forceinline__ void pp_load(PPData &d, const DevProblem &p, const PP
             d.aq[2 * b] = rowsA[(long)(2 * b) * S + r.ipb + q];
             d.aq[2 * b + 1] = rowsA[(long)(2 * b + 1) * S + r.ipb + q];
         }
+        if (FUSED) {
+            const d2_t *u = reinterpret_cast<const d2_t *>(Ubuf + (long)2 * (r.ipb + q) * 8);
+#pragma unroll
+            for (int k = 0; k < 3; k++) { d.uq[k] = u[k]; d.uq[3 + k] = u[4 + k]; }
+        }
     } else {
         d.cq[0] = d.cq[1] = d.cq[2] = -1;
     }
 }
 
-__device__ __forceinline__ void pp_load_row(double (&ap)[6], const DevProblem &p, const PPRecord &r,
-                                            const double *__restrict__ rowsA, double sigma2) {
+// The row point's own operands are the same for the 64 lanes of a wave: A_p (6 values) and, FUSED, its two rows of U (12).
+// They are fetched ahead as ONE vector load (lane l < 6: A_p[l]; lanes 8..19: U) and spread to scalar registers with
+// v_readlane when the wave moves on to that image -- prefetching them as scalars would need 36 more SGPRs than there are.
+template <bool FUSED>
+__device__ __forceinline__ double pp_fetch_row(const DevProblem &p, const PPRecord &r, const double *__restrict__ rowsA,
+                                               const double *__restrict__ Ubuf, int lane) {
     const long S = p.n_ip;
     const int ip = r.ipb + r.lp;
+    const int k = lane - 8;
+    const double *src = lane < 6 ? rowsA + (long)lane * S + ip
+                                 : (FUSED && k >= 0 && k < 12 ? Ubuf + (long)2 * ip * 8 + (k < 6 ? k : k + 2) : nullptr);
+    return src ? *src : 0.0;
+}
+__device__ __forceinline__ double pp_lane(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+template <bool FUSED>
+__device__ __forceinline__ void pp_spread_row(double rowvec, double sigma2, double (&ap)[6], double (&up)[12]) {
 #pragma unroll
-    for (int a = 0; a < 6; a++) ap[a] = sigma2 * rowsA[(long)a * S + ip];
+    for (int a = 0; a < 6; a++) ap[a] = (FUSED ? 1.0 : sigma2) * pp_lane(rowvec, a);   // FUSED: the factor goes onto Dinv
+    if (FUSED) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) up[k] = pp_lane(rowvec, 8 + k);
+    }
 }
 
-__device__ __forceinline__ void pp_accumulate(const PPData &d, const double (&ap)[6], double *strip, int c0, int cp0, int cp1,
-                                              int cp2) {
+template <bool FUSED>
+__device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const double (&ap)[6], const double (&up)[12], double sigma2,
+                                              double *strip, int c0, int cp0, int cp1, int cp2) {
+    double p00 = d.P0.x, p01 = d.P0.y, p10 = d.P1.x, p11 = d.P1.y;
+    if (FUSED) {
+        p00 *= sigma2; p01 *= sigma2; p10 *= sigma2; p11 *= sigma2;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            p00 -= up[2 * k] * d.uq[k].x + up[2 * k + 1] * d.uq[k].y;
+            p01 -= up[2 * k] * d.uq[3 + k].x + up[2 * k + 1] * d.uq[3 + k].y;
+            p10 -= up[6 + 2 * k] * d.uq[k].x + up[6 + 2 * k + 1] * d.uq[k].y;
+            p11 -= up[6 + 2 * k] * d.uq[3 + k].x + up[6 + 2 * k + 1] * d.uq[3 + k].y;
+        }
+    }
 #pragma unroll
     for (int b = 0; b < 3; b++) {
         const int cq = d.cq[b];
         if (cq < c0 || cq >= c0 + PP_CW) continue;
-        const double g0 = d.P0.x * d.aq[2 * b] + d.P0.y * d.aq[2 * b + 1];
-        const double g1 = d.P1.x * d.aq[2 * b] + d.P1.y * d.aq[2 * b + 1];
+        const double g0 = p00 * d.aq[2 * b] + p01 * d.aq[2 * b + 1];
+        const double g1 = p10 * d.aq[2 * b] + p11 * d.aq[2 * b + 1];
         if (cp0 >= cq) unsafeAtomicAdd(&strip[cq - c0], ap[0] * g0 + ap[1] * g1);
         if (cp1 >= cq) unsafeAtomicAdd(&strip[PP_CW + cq - c0], ap[2] * g0 + ap[3] * g1);
         if (cp2 >= cq) unsafeAtomicAdd(&strip[2 * PP_CW + cq - c0], ap[4] * g0 + ap[5] * g1);
     }
 }
 
+// everything a wave derives from its image record is the same for its 64 lanes: held in scalar registers (the compiler cannot
+// see that `wave` is uniform), which is what leaves the vector registers for the U rows at four workgroups per CU
+__device__ __forceinline__ PPRecord pp_record(const PPRecord *recs, int o) {
+    const int4 *src = reinterpret_cast<const int4 *>(recs + o);
+    const int4 a = src[0], b = src[1];
+    PPRecord r;
+    r.ipb = __builtin_amdgcn_readfirstlane(a.x); r.mp = __builtin_amdgcn_readfirstlane(a.y);
+    r.lp = __builtin_amdgcn_readfirstlane(a.z); r.pad = 0;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane(b.x), hi = (unsigned)__builtin_amdgcn_readfirstlane(b.y);
+    r.poff = (int64_t)(((unsigned long long)hi << 32) | lo);
+    r.pad2 = 0;
+    return r;
+}
+__device__ __forceinline__ int2 pp_range(const int2 *range, long idx) {
+    const int2 g = range[idx];
+    return make_int2(__builtin_amdgcn_readfirstlane(g.x), __builtin_amdgcn_readfirstlane(g.y));
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
-                                                            double sigma2, double *__restrict__ N) {
+                                                            const double *__restrict__ Ubuf, double sigma2, double *__restrict__ N) {
     __shared__ double strip[3 * PP_CW];
     constexpr int NW = PP_NT / 64;
-    const int pt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, chunk = blockIdx.y, nch = pp.n_chunks;
+    const int pt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, chunk = blockIdx.y, nch = pp.n_chunks;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c0 = pp.cmin + chunk * PP_CW;
     const int cp0 = p.point_col[3 * pt], cp1 = p.point_col[3 * pt + 1], cp2 = p.point_col[3 * pt + 2];
     const int rmax = max(cp0, max(cp1, cp2));
@@ -417,33 +481,32 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     __syncthreads();
     if (ob + wave < oe) {
         const int o0 = ob + wave;
-        PPRecord r1 = pp.recs[o0];
-        int2 g1 = range[(long)o0 * nch + chunk];
+        PPRecord r1 = pp_record(pp.recs, o0);
+        int2 g1 = pp_range(range, (long)o0 * nch + chunk);
         const int o1 = min(o0 + NW, oe - 1);
-        PPRecord r2 = pp.recs[o1];
-        int2 g2 = range[(long)o1 * nch + chunk];
-        PPData cur, nxt;
-        double apc[6], apn[6];
-        pp_load(cur, p, r1, pp.ipcol, rowsA, g1.x + lane, g1.y);
-        pp_load_row(apc, p, r1, rowsA, sigma2);
+        PPRecord r2 = pp_record(pp.recs, o1);
+        int2 g2 = pp_range(range, (long)o1 * nch + chunk);
+        PPData<FUSED> cur, nxt;
+        double apc[6], upc[12];
+        pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y);
+        pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
         for (int o = o0; o < oe; o += NW) {
             const int o2 = min(o + 2 * NW, oe - 1);
-            const PPRecord r3 = pp.recs[o2];
-            const int2 g3 = range[(long)o2 * nch + chunk];
+            const PPRecord r3 = pp_record(pp.recs, o2);
+            const int2 g3 = pp_range(range, (long)o2 * nch + chunk);
+            double rown = 0.0;
             if (o + NW < oe) {
-                pp_load(nxt, p, r2, pp.ipcol, rowsA, g2.x + lane, g2.y);
-                pp_load_row(apn, p, r2, rowsA, sigma2);
+                pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y);
+                rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
             }
-            pp_accumulate(cur, apc, strip, c0, cp0, cp1, cp2);
-            // ranges longer than a wave: the remaining passes without prefetch
+            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2);
+            // ranges longer than a wave: the remaining passes without prefetch (into the registers of `cur`, which is done)
             for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
-                PPData extra;
-                pp_load(extra, p, r1, pp.ipcol, rowsA, j, g1.y);
-                pp_accumulate(extra, apc, strip, c0, cp0, cp1, cp2);
+                pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y);
+                pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2);
             }
             cur = nxt;
-#pragma unroll
-            for (int a = 0; a < 6; a++) apc[a] = apn[a];
+            pp_spread_row<FUSED>(rown, sigma2, apc, upc);
             r1 = r2; g1 = g2; r2 = r3; g2 = g3;
         }
     }
@@ -638,15 +701,15 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb) {
     if (n_list <= 0) return hipSuccess;
-    const int schur = sb.Pp != nullptr;
+    const int schur = sb.active ? 1 : 0;
     hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
     DevProblem q = p;
     double s2 = sigma2;
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
         hipError_t he = launch_schur_eliminate(s, p, blk_list, n_list, max_m, ip_list, n_ip_list, rowsA, rowsW, T, sigma2,
-                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.Pp, sb.info, sb.diagcorr);
+                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr);
         if (he != hipSuccess) return he;
-        q.blk_w = sb.Pp;
+        if (sb.materialise) q.blk_w = sb.Pp;
         s2 = 1.0;
     }
     static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::max(1, atoi(getenv("JAICOV_CC_PARTS"))) : 8;
@@ -660,8 +723,13 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
                            ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
     if (pp.pt_ip_begin) {
-        hipLaunchKernelGGL(blk_pp_gather_kernel, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp, rowsA, s2, N);
+        if (schur && !sb.materialise)   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
+            hipLaunchKernelGGL(blk_pp_gather_kernel<true>, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, p, pp, rowsA, sb.U, sigma2, N);
+        else
+            hipLaunchKernelGGL(blk_pp_gather_kernel<false>, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp, rowsA,
+                               (const double *)nullptr, s2, N);
     } else {
+        if (schur && !sb.materialise) return hipErrorInvalidValue;   // the per-pair atomic kernel reads a materialised P'
         const int mp = max_m / 2;
         hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, q, blk_list, rowsA, s2, N);
     }

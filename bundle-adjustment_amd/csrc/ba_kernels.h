@@ -70,6 +70,8 @@ struct SchurBufs {
     double *U = nullptr, *Linv = nullptr, *G = nullptr, *Pp = nullptr, *diagcorr = nullptr;
     int *info = nullptr;
     double lambda = 0.0;
+    bool active = false;      // this pass pre-eliminates the exterior orientations
+    int materialise = 0;      // P' = sigma2 Dinv - U U' is written out (Pp) instead of being formed inside the point x point gather
 };
 
 // assembly_mode = 1 (densemode.hip): workspace and driver of the densified MFMA contraction of the image groups

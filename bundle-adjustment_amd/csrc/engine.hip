@@ -643,7 +643,11 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     //      trailing columns e0 + 6*image + k, and no directly observed parameter is an EO parameter ------------------
     {
         const char *env = getenv("JAICOV_SCHUR");
-        bool ok = !(env && env[0] == '0') && D->n_images > 0 && D->n_image_blocks > 0 && e->n_seg == 0 && e->n_blk_ip == e->ip_count;
+        // Eligibility is a property of the WHOLE problem, not of this engine's image range: every rank of a sharded run must
+        // reach the same decision, or their reduce buffers differ in length (and only some ranks enter the EO exchange).
+        size_t n_in_block = 0;
+        for (int ip = 0; ip < D->n_image_points; ip++) n_in_block += in_block[ip] ? 1 : 0;
+        bool ok = !(env && env[0] == '0') && D->n_images > 0 && D->n_image_blocks > 0 && n_in_block == (size_t)D->n_image_points;
         if ((e->opts.assembly_mode == 1 || e->opts.assembly_mode == 2) && e->n_blk_list > 0) {   // densified MFMA contraction of the image groups (densemode.hip)
             int max_k1 = 0;
             for (int g : blk_list) {
@@ -667,7 +671,9 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = dalloc(e, (size_t)16 * std::max(1, D->n_image_points), &e->sb.U, true))) return rc;
             if ((rc = dalloc(e, (size_t)36 * D->n_images, &e->sb.Linv, true))) return rc;
             if ((rc = dalloc(e, (size_t)6 * SCHUR_GLD * D->n_images, &e->sb.G, true))) return rc;
-            if ((rc = dalloc(e, (size_t)std::max<int64_t>(w_total_saved, 1), &e->sb.Pp))) return rc;
+            // P' = sigma2 Dinv - U U' is formed inside the point x point gather; a copy in memory (4 GB at config 4) only on request
+            e->sb.materialise = (getenv("JAICOV_PP_MATERIALISE") || getenv("JAICOV_PP_ATOMIC")) ? 1 : 0;
+            if (e->sb.materialise && (rc = dalloc(e, (size_t)std::max<int64_t>(w_total_saved, 1), &e->sb.Pp))) return rc;
             if ((rc = dalloc(e, (size_t)6 * D->n_images, &e->d_xE, true))) return rc;
             if ((rc = dalloc(e, (size_t)1, &e->sb.info, true))) return rc;
             if ((rc = dalloc(e, (size_t)e->Upad, &e->sb.diagcorr, true))) return rc;
@@ -758,7 +764,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     if (!plain)
         HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     SchurBufs sb = e->sb;
-    if (!e->schur_active) sb.Pp = nullptr;
+    sb.active = e->schur_active;
     sb.lambda = e->lambda_acc;
     if (e->schur_active) {
         HIPE(e, hipMemsetAsync(e->sb.info, 0, sizeof(int), e->stream));

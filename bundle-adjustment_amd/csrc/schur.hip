@@ -280,8 +280,9 @@ hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int3
     if (n_list <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_elim_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T, sigma2, lambda, Ubuf,
                        Linv, G, info);
-    hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 63) / 64, n_list), dim3(64, 4), 0, s, p, blk_list,
-                       Ubuf, sigma2, Pp);
+    if (Pp)   // only when P' is wanted in memory (JAICOV_PP_MATERIALISE / the atomic point x point kernel); the gather forms it on the fly
+        hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 63) / 64, n_list), dim3(64, 4), 0, s, p, blk_list,
+                           Ubuf, sigma2, Pp);
     if (lambda > 0.0 && diagcorr) {
         const long nt = (long)3 * n_ip_list + (long)n_list * SCHUR_GLD;
         hipLaunchKernelGGL(blk_diagcorr_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, p, ip_list, n_ip_list,

@@ -71,6 +71,23 @@ def allreduce_engine_buffer(eng, dist, device):
     torch.cuda.synchronize(device)
 
 
+def _check_same_buffer_on_all_ranks(eng, dist, device):
+    """Every rank must hold the same system (same reduced order, hence the same reduce-buffer length) before the
+    collective: ranks that disagree would hang in RCCL or sum unrelated entries.  Checked once per engine and order."""
+    import torch
+    order = eng.reduced_order()
+    if getattr(eng, "_order_agreed", None) == order or dist.get_world_size() == 1:
+        return
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([order, -order], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hi, lo = int(t[0]), -int(t[1])
+    if hi != lo:
+        raise RuntimeError(f"ranks disagree on the order of the assembled system ({lo} .. {hi}): the engines were created "
+                           "from different problem descriptions or inversion modes")
+    eng._order_agreed = order
+
+
 def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
     """One pass of the loop body on a sharded engine: accumulate -> all-reduce -> finalize -> solve.
 
@@ -79,6 +96,7 @@ def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
     import torch
     eng.prepare_inverse(invert)
     eng.accumulate(sigma2, lam)
+    _check_same_buffer_on_all_ranks(eng, dist, device)
     allreduce_engine_buffer(eng, dist, device)
     eng.finalize(sigma2, lam)
     dx = eng.solve(invert)

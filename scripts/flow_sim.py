@@ -201,3 +201,49 @@ if __name__ == "__main__":
             simulate(schedule_hybrid(nb, rows, E, 4, spread), nb, rows, verbose=True, label=f"hybrid: {E} panels of 4 right-looking")
     for E in (2, 4):
         simulate(schedule_hybrid(nb, rows, E, 8), nb, rows, verbose=True, label=f"hybrid: {E} panels of 8 right-looking")
+
+
+def schedule_prefill(nb, rows, G=4, D=6, slots=510, chain=125.0, cmax=40, frac=1.0, order="near"):
+    """Column-major left-looking, with the slot time the chain leaves idle in the early columns filled by partial visits:
+    after the tasks of column c, tiles of columns >= c + D get the block columns [applied, b) that are final by then
+    (b = multiple of G, b <= c), as many tiles as fit into the idle time of one chain link."""
+    t = []
+    applied = {}
+    for c in range(nb):
+        for i in range(c, rows):
+            t.append((i, c, applied.get((i, c), 0), c | FIN))
+        if c >= cmax:
+            continue
+        b = (c // G) * G
+        if b <= 0:
+            continue
+        own = (rows - c) * max(c - 0, 1) * STEP_PAIRED          # this column's own work (upper estimate)
+        idle = max(0.0, slots * chain - own) * frac
+        cand = []
+        cols = range(c + D, nb) if order == "near" else range(nb - 1, c + D - 1, -1)
+        for j in cols:
+            for i in range(j, rows):
+                a = applied.get((i, j), 0)
+                if a < b:
+                    cand.append((i, j, a))
+            if len(cand) * (STEP_PAIRED * G + 12) > idle:
+                break
+        for (i, j, a) in cand:
+            cost = (b - a) * STEP_PAIRED + 12
+            if idle < cost:
+                break
+            idle -= cost
+            t.append((i, j, a, b))
+            applied[(i, j)] = b
+    return t
+
+
+if __name__ == "__main__":
+    nb = int(sys.argv[1]) if len(sys.argv) > 1 else 118
+    rows = nb + 1
+    print("---- prefill")
+    for G in (2, 4, 8):
+        for D in (4, 8):
+            for frac in (0.5, 1.0, 1.5):
+                for cmax in (24, 40):
+                    simulate(schedule_prefill(nb, rows, G, D, cmax=cmax, frac=frac), nb, rows, verbose=True, label=f"prefill G={G} D={D} frac={frac} cmax={cmax}")
