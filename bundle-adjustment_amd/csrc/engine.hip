@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <string>
 #include <vector>
@@ -205,6 +206,7 @@ struct jaicov_engine {
     bool solver_has_inverse = false;
     enum { ST_NEW, ST_PARAMS, ST_ACCUMULATED, ST_BUILT, ST_SOLVED } state = ST_NEW;
     bool have_Q = false, rows_valid = false, reduced = false;
+    std::atomic<int> cancel{0};  // BundleAdjustment.interrupt() (BA:1455): polled by estimate() where the reference polls (BA:240, 320)
     bool sim_built = false;      // the system at hand was built with simulation != 0: the right-hand side is zero for ALL unknowns (BA:830-831)
     double lambda_used = 0.0;
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
@@ -1321,6 +1323,7 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
         rc = jaicov_neq_build(e, sigma2, adapted, o->simulation);
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
         if (rc) { state = rc == JAICOV_ERR_BAD_ARGUMENT || rc > 0 ? -2 : -1; break; }
+        if (e->cancel.exchange(0)) { state = -1; rc = JAICOV_OK; break; }       // BA:240-245: INTERRUPT, flag cleared
         complete = isEstimated;
         rc = jaicov_neq_solve(e, complete ? o->invert : JAICOV_INVERT_NONE, dx.data());
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
@@ -1351,6 +1354,7 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
             lastValid = maxAbsDx;
         }
         res->seconds_last_pass = std::chrono::duration<double>(std::chrono::steady_clock::now() - tp).count();
+        if (e->cancel.exchange(0)) { state = -1; rc = JAICOV_OK; break; }       // BA:320-325
         if (std::isinf(maxAbsDx) || std::isnan(maxAbsDx)) { state = -2; break; }
         else if (maxAbsDx <= SQRT_EPS && runs > 0 && adapted == 0) isEstimated = true;
         else if (runs-- <= 1) {
@@ -1366,7 +1370,14 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
     res->max_abs_dx = maxAbsDx;
     res->final_lambda = adapted;
     res->seconds_total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    return (state == 1 || state == -4 || state == -2) ? JAICOV_OK : rc;
+    return (state == 1 || state == -4 || state == -2 || state == -1) ? (state == -1 && rc ? rc : JAICOV_OK) : rc;
+}
+
+// BundleAdjustment.interrupt() (BA:1455-1457): may be called from another thread while estimate() runs
+extern "C" int jaicov_neq_cancel(jaicov_engine *e) {
+    if (!e) return JAICOV_ERR_BAD_ARGUMENT;
+    e->cancel.store(1);
+    return JAICOV_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------

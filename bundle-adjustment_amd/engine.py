@@ -26,7 +26,7 @@ EXPORTS = [
     "jaicov_neq_finalize", "jaicov_neq_reduce_buffer", "jaicov_neq_reduce_buffer_async",
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_dispersion_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
-    "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats",
+    "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats", "jaicov_neq_cancel",
     "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm",
 ]
 
@@ -111,6 +111,7 @@ def load_library():
     L.jaicov_neq_last_timings.argtypes = [vp, _pd, C.c_int32]
     L.jaicov_neq_set_profiling.argtypes = [vp, C.c_int]
     L.jaicov_neq_kernel_stats.argtypes = [vp, _pd, C.c_int32, C.c_int]
+    L.jaicov_neq_cancel.argtypes = [vp]
     L.jaicov_dense_spd_solve_packed.argtypes = [C.c_int32, _pd, _pd, C.c_int32, C.c_int32, _pd]
     L.jaicov_dense_gemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, _pd, C.c_int64,
                                     _pd, C.c_int64, C.c_double, _pd, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _pd]
@@ -265,6 +266,10 @@ class Engine:
         st = np.zeros(6)
         self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 6, int(reset)))
         return {"launches": st[0], "ms": st[1], "flops": st[2], "dense_passes": st[3], "dense_gemm_ms": st[4], "dense_flops": st[5]}
+
+    def cancel(self):
+        """``BundleAdjustment.interrupt()`` (BundleAdjustment.java:1455): the running / next ``estimate`` ends with state -1."""
+        self._chk(self.L.jaicov_neq_cancel(self._h))
 
     def estimate(self, values=None, sigma2=None, lam0=0.0, max_iter=5000, invert=True, simulation=False):
         """``BundleAdjustment.estimateModel()`` (BundleAdjustment.java:203-387) run natively on the engine."""

@@ -270,6 +270,10 @@ typedef struct jaicov_estimate_result {
 } jaicov_estimate_result;
 
 int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_options *opts, jaicov_estimate_result *res);
+/* BundleAdjustment.interrupt() (BA:1455-1457): sets the cooperative cancel flag; jaicov_neq_estimate polls it where the
+ * reference polls `interrupt` (after the build, BA:240, and after the update, BA:320), ends with state -1 (INTERRUPT) and
+ * clears it.  The only entry point that may be called from another thread while a call on the same engine is running.     */
+int jaicov_neq_cancel(jaicov_engine *e);
 
 /* timing of the stages of the last pass in milliseconds (HIP events on the engine stream):
  * [0] rows  [1] assembly  [2] finalize  [3] factorisation  [4] solve  [5] inverse  [6] omega  [7] total  */

@@ -1,0 +1,45 @@
+/* Minimal stand-in for <jni.h>: TEST INFRASTRUCTURE ONLY (tests/test_jni_binding.py compiles java/jni/jaicov_jni.c with
+ * -fsyntax-only against it because the build image has no JDK).  It declares exactly the JNI 1.6 entries the shim uses, with
+ * the signatures of the JNI specification; it is never linked and never shipped. */
+#ifndef JAICOV_TEST_JNI_STUB_H
+#define JAICOV_TEST_JNI_STUB_H
+#include <stdint.h>
+typedef int32_t jint;
+typedef int64_t jlong;
+typedef int8_t jbyte;
+typedef uint8_t jboolean;
+typedef double jdouble;
+typedef jint jsize;
+struct _jobject;
+typedef struct _jobject *jobject;
+typedef jobject jclass, jstring, jarray, jintArray, jlongArray, jbyteArray, jdoubleArray;
+struct _jfieldID;
+typedef struct _jfieldID *jfieldID;
+#define JNIEXPORT __attribute__((visibility("default")))
+#define JNICALL
+#define JNI_ABORT 2
+struct JNINativeInterface_;
+typedef const struct JNINativeInterface_ *JNIEnv;
+struct JNINativeInterface_ {
+    jclass (*FindClass)(JNIEnv *, const char *);
+    jint (*ThrowNew)(JNIEnv *, jclass, const char *);
+    jclass (*GetObjectClass)(JNIEnv *, jobject);
+    jfieldID (*GetFieldID)(JNIEnv *, jclass, const char *, const char *);
+    jobject (*GetObjectField)(JNIEnv *, jobject, jfieldID);
+    jint (*GetIntField)(JNIEnv *, jobject, jfieldID);
+    jstring (*NewStringUTF)(JNIEnv *, const char *);
+    jsize (*GetArrayLength)(JNIEnv *, jarray);
+    jint *(*GetIntArrayElements)(JNIEnv *, jintArray, jboolean *);
+    jlong *(*GetLongArrayElements)(JNIEnv *, jlongArray, jboolean *);
+    jbyte *(*GetByteArrayElements)(JNIEnv *, jbyteArray, jboolean *);
+    jdouble *(*GetDoubleArrayElements)(JNIEnv *, jdoubleArray, jboolean *);
+    void (*ReleaseIntArrayElements)(JNIEnv *, jintArray, jint *, jint);
+    void (*ReleaseLongArrayElements)(JNIEnv *, jlongArray, jlong *, jint);
+    void (*ReleaseByteArrayElements)(JNIEnv *, jbyteArray, jbyte *, jint);
+    void (*ReleaseDoubleArrayElements)(JNIEnv *, jdoubleArray, jdouble *, jint);
+    void (*SetDoubleArrayRegion)(JNIEnv *, jdoubleArray, jsize, jsize, const jdouble *);
+    void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);
+    void *(*GetPrimitiveArrayCritical)(JNIEnv *, jarray, jboolean *);
+    void (*ReleasePrimitiveArrayCritical)(JNIEnv *, jarray, void *, jint);
+};
+#endif

@@ -195,6 +195,19 @@ def test_simulation_leaves_parameters_and_gives_the_oracles_cofactors(oracle_mod
     eng.close()
 
 
+def test_interrupt_ends_the_loop_with_state_interrupt():
+    """BundleAdjustment.interrupt() (BundleAdjustment.java:1455, polled at :240 and :320) = jaicov_neq_cancel."""
+    fp = scene.config("tiny")
+    eng = engine.Engine(fp)
+    eng.cancel()
+    v, r = eng.estimate()
+    assert r.state == -1 and r.iterations == 1          # EstimationStateType.INTERRUPT after the first build
+    np.testing.assert_array_equal(v, fp.values)         # BA:240 returns before the solve: nothing was updated
+    v, r = eng.estimate()                               # the flag was cleared (BA:243 this.interrupt = false)
+    assert r.state == 1
+    eng.close()
+
+
 def test_sharded_engines_sum_to_full(oracle_mod):
     fp = scene.config("tiny_block")
     s2 = fp.sigma2apriori
