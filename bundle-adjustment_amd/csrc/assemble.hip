@@ -695,7 +695,7 @@ hipError_t launch_assemble_small(hipStream_t s, const DevProblem &p, const int32
 
 hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
                                   const double *, const double *, double *, double, double, double *, double *, double *,
-                                  double *, int *, double *);
+                                  double *, int *, double *, double *);
 
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
@@ -707,7 +707,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     double s2 = sigma2;
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
         hipError_t he = launch_schur_eliminate(s, p, blk_list, n_list, max_m, ip_list, n_ip_list, rowsA, rowsW, T, sigma2,
-                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr);
+                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr, sb.xq);
         if (he != hipSuccess) return he;
         if (sb.materialise) q.blk_w = sb.Pp;
         s2 = 1.0;

@@ -68,6 +68,7 @@ struct PPGather {
 // buffers of the per-image EO pre-elimination (schur.hip); Pp == nullptr -> mode off
 struct SchurBufs {
     double *U = nullptr, *Linv = nullptr, *G = nullptr, *Pp = nullptr, *diagcorr = nullptr;
+    double *xq = nullptr;     // [6 * images] n_E / diag(N_EE): what the reference's REDUCED last pass leaves in dx (engine option)
     int *info = nullptr;
     double lambda = 0.0;
     bool active = false;      // this pass pre-eliminates the exterior orientations

@@ -677,6 +677,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             e->sb.materialise = (getenv("JAICOV_PP_MATERIALISE") || getenv("JAICOV_PP_ATOMIC")) ? 1 : 0;
             if (e->sb.materialise && (rc = dalloc(e, (size_t)std::max<int64_t>(w_total_saved, 1), &e->sb.Pp))) return rc;
             if ((rc = dalloc(e, (size_t)6 * D->n_images, &e->d_xE, true))) return rc;
+            if (e->opts.reduced_reference_quirk && (rc = dalloc(e, (size_t)6 * D->n_images, &e->sb.xq, true))) return rc;
             if ((rc = dalloc(e, (size_t)1, &e->sb.info, true))) return rc;
             if ((rc = dalloc(e, (size_t)e->Upad, &e->sb.diagcorr, true))) return rc;
             e->schur_ok = true;
@@ -863,10 +864,29 @@ extern "C" int jaicov_neq_finalize(jaicov_engine *e, double sigma2, double lambd
     return JAICOV_OK;
 }
 
+// buffers of the inverse (W = L^-1 and Q, two squares of the solver's order) of the solver that the announced mode will use
+static int ensure_inverse_buffers(jaicov_engine *e, bool reduced_system) {
+    DenseSolver &slv = reduced_system ? e->solverS : e->solver;
+    bool &has_inv = reduced_system ? e->solverS_has_inverse : e->solver_has_inverse;
+    if (has_inv) return JAICOV_OK;
+    const size_t sq = (size_t)slv.n * slv.ld * sizeof(double);
+    HIPE(e, hipMalloc(&slv.W, sq));
+    HIPE(e, hipMalloc(&slv.Q, sq));
+    has_inv = true;
+    return JAICOV_OK;
+}
+
 extern "C" int jaicov_neq_prepare_inverse(jaicov_engine *e, int inverse_follows) {
     if (!e) return JAICOV_ERR_BAD_ARGUMENT;
     if (inverse_follows < 0 || inverse_follows > JAICOV_INVERT_REDUCED) return JAICOV_ERR_BAD_ARGUMENT;
     e->inverse_mode_next = inverse_follows;
+    // the inverse's buffers are allocated HERE, when the final pass is announced (BA:250: known before the build), not inside
+    // the solve: hipMalloc of 2 x 1.8 .. 2.6 GB cost the first inverting solve 45 ms at config 4
+    if (inverse_follows != JAICOV_INVERT_NONE) {
+        HIPE(e, hipSetDevice(e->device));
+        const bool reduced = e->schur_ok && inverse_follows == JAICOV_INVERT_REDUCED && e->solverS_ready;
+        return ensure_inverse_buffers(e, reduced);
+    }
     return JAICOV_OK;
 }
 
@@ -976,12 +996,9 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     slv.flops_order = (double)(schur ? e->e0 : e->U);
     const int Up = slv.nfact;                      // padded order of the factorised system
     const long ld = slv.ld;
-    bool &has_inv = schur ? e->solverS_has_inverse : e->solver_has_inverse;
-    if (invert && !has_inv) {
-        const size_t sq = (size_t)slv.n * slv.ld * sizeof(double);
-        HIPE(e, hipMalloc(&slv.W, sq));
-        HIPE(e, hipMalloc(&slv.Q, sq));
-        has_inv = true;
+    if (invert) {   // normally done by prepare_inverse(); a host that did not announce the final pass pays the allocation here
+        const int rc_inv = ensure_inverse_buffers(e, schur);
+        if (rc_inv) return rc_inv;
     }
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
     HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1070,6 +1087,14 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         // SIMULATION zeroes the right-hand side of the WHOLE system (BA:830-831 `n.zero()`): the eliminated exterior
         // orientations get no step either (their back substitution would use the real misclosures)
         for (int c = U; c < e->U; c++) dx_out[c] = 0.0;
+    } else if (schur && e->opts.reduced_reference_quirk && invert == JAICOV_INVERT_REDUCED) {
+        // what the reference's last pass leaves in the EO entries of dx under MatrixInversion.REDUCED (quirk Q1): V_c^2 n_c
+        std::vector<double> xq((size_t)6 * e->p.n_images);
+        HIPE(e, hipMemcpyAsync(xq.data(), e->sb.xq, xq.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        for (int c = U; c < e->U; c++) dx_out[c] = 0.0;
+        for (int img : e->h_blk_images)
+            for (int k = 0; k < 6; k++) dx_out[e->e0 + 6 * img + k] = xq[(size_t)6 * img + k];
     } else if (schur) {
         // EO step of every image of this engine: dx_E = L_E^-T U' (w - A_r dx_R)   (schur.hip)
         for (int c = U; c < e->U; c++) dx_out[c] = 0.0;
@@ -1085,6 +1110,17 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
                 dx_out[e->e0 + 6 * img + k] = xE[(size_t)6 * img + k];
                 if (!std::isfinite(xE[(size_t)6 * img + k])) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite step");
             }
+    }
+    if (!schur && e->opts.reduced_reference_quirk && invert == JAICOV_INVERT_REDUCED) {
+        // full-order path (no EO pre-elimination possible): the same quirk from the assembled right-hand side, V_c^2 n_c
+        std::vector<double> hn((size_t)e->U);
+        HIPE(e, hipMemcpyAsync(hn.data(), e->d_n, hn.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        const int ns = e->n_slots, s_eo = ns - 6 * e->p.n_images;
+        for (int sl = s_eo; sl < ns; sl++) {
+            const int c = e->h_slot_col[sl];
+            if (c >= 0) dx_out[c] = e->h_V[c] * e->h_V[c] * hn[c];
+        }
     }
     if (invert) {
         // FULL: Qxx of all unknowns.  REDUCED on a pre-eliminated system: the inverse of the reduced normal equations,

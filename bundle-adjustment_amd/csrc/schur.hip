@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
                                                        const double *__restrict__ rowsA, const double *__restrict__ rowsW,
                                                        const double *__restrict__ T, double sigma2, double lambda,
                                                        double *__restrict__ Ubuf, double *__restrict__ Linv_out,
-                                                       double *__restrict__ G_out, int *info) {
+                                                       double *__restrict__ G_out, int *info, double *__restrict__ xq) {
     __shared__ double red[42];        // E (36) + nE (6)
     __shared__ double Linv[36];
     __shared__ double Gs[6 * SCHUR_GLD];
@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
             for (int j = 0; j < 6; j++) E[k][j] = sigma2 * 0.5 * (red[6 * k + j] + red[6 * j + k]);
         if (lambda > 0.0)
             for (int k = 0; k < 6; k++) E[k][k] += lambda * E[k][k];
+        if (xq)   // V_c^2 n_c with V_c = 1/sqrt(N_cc) where N_cc > EPS, else 1 (BA:825-828, NES:82-91 twice; quirk Q1)
+            for (int k = 0; k < 6; k++) {
+                const double nE = sigma2 * red[36 + k];
+                xq[(long)img * 6 + k] = E[k][k] > 1.1102230246251565e-16 ? nE / E[k][k] : nE;
+            }
         bool ok = true;
         for (int j = 0; j < 6; j++) {
             double d = E[j][j];
@@ -276,10 +281,10 @@ __global__ __launch_bounds__(256) void blk_diagcorr_kernel(DevProblem p, const i
 hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double lambda, double *Ubuf, double *Linv, double *G,
-                                  double *Pp, int *info, double *diagcorr) {
+                                  double *Pp, int *info, double *diagcorr, double *xq) {
     if (n_list <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_elim_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T, sigma2, lambda, Ubuf,
-                       Linv, G, info);
+                       Linv, G, info, xq);
     if (Pp)   // only when P' is wanted in memory (JAICOV_PP_MATERIALISE / the atomic point x point kernel); the gather forms it on the fly
         hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 63) / 64, n_list), dim3(64, 4), 0, s, p, blk_list,
                            Ubuf, sigma2, Pp);

@@ -46,7 +46,7 @@ class EngineError(RuntimeError):
 class EngineOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("image_begin", C.c_int32),
                 ("image_end", C.c_int32), ("apply_shared", C.c_int32), ("assembly_mode", C.c_int32),
-                ("block_size", C.c_int32), ("reserved", C.c_int32 * 8)]
+                ("block_size", C.c_int32), ("reduced_reference_quirk", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 class EstimateOptions(C.Structure):
@@ -126,7 +126,8 @@ def _p(a):
 class Engine:
     """One engine per adjustment (``BundleAdjustment`` is single-shot: BundleAdjustment.java:203)."""
 
-    def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0):
+    def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0,
+                 reduced_reference_quirk: bool = False):
         self.L = load_library()
         self.fp = fp
         self.U = fp.n_unknowns
@@ -137,6 +138,7 @@ class Engine:
         opts.image_begin, opts.image_end = image_range if image_range is not None else (-1, -1)
         opts.apply_shared = int(apply_shared)
         opts.assembly_mode = int(assembly_mode)
+        opts.reduced_reference_quirk = int(reduced_reference_quirk)
         self._h = C.c_void_p()
         rc = self.L.jaicov_neq_create(C.byref(self._desc), C.byref(opts), C.byref(self._h))
         if rc != 0:

@@ -141,6 +141,7 @@ PYBIND11_MODULE(_jaicov_host, m) {
             return py::array_t<double>({idx.size(), idx.size()}, v.data());
         }, py::arg("indices"), py::arg("scale") = 1.0)
         .def("useCentroidedCoordinates", &BundleAdjustment::useCentroidedCoordinates)
+        .def("centroidCoordinates", &BundleAdjustment::centroidCoordinates)
         .def("applyAposterioriVarianceOfUnitWeight", &BundleAdjustment::applyAposterioriVarianceOfUnitWeight)
         .def("setLevenbergMarquardtDampingValue", &BundleAdjustment::setLevenbergMarquardtDampingValue)
         .def("setMaximalNumberOfIterations", &BundleAdjustment::setMaximalNumberOfIterations)

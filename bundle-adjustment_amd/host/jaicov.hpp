@@ -451,6 +451,7 @@ public:
     void setInvertNormalEquation(MatrixInversion m) { inversion_ = m; }                 // BA:1146
     MatrixInversion getInvertNormalEquation() const { return inversion_; }
     void useCentroidedCoordinates(bool b) { centroided_ = b; }                          // BA:1181
+    void centroidCoordinates(bool invert);    // BA:115-201 (private in the reference; public here so that the parity tests can call it)
     void applyAposterioriVarianceOfUnitWeight(bool b) { applyAposteriori_ = b; }        // BA:1185
     void setLevenbergMarquardtDampingValue(double l) { damping_ = std::fabs(l); }       // BA:1189
     double getLevenbergMarquardtDampingValue() const { return damping_; }
@@ -518,7 +519,6 @@ private:
     }
     void noteVariance(double v) { sigma2apriori_ = std::min(sigma2apriori_, v); }      // BA:641
     void detectRankDefect();                  // BA:836-1042
-    void centroidCoordinates(bool invert);    // BA:115-201
     void pushValues();                        // objects -> flat.values
     void pullValues(const std::vector<double> &v);
 

@@ -152,7 +152,12 @@ typedef struct jaicov_engine_options {
                                       2 = mode 1 with operands rounded to fp32 and fp32 MFMA accumulation (BASELINE config 5's
                                       precision sweep; NOT a product mode, results differ at the 1e-7 level by design)       */
     int32_t  block_size;           /* factorisation block NB; 0 = default                                */
-    int32_t  reserved[8];
+    int32_t  reduced_reference_quirk; /* != 0: a solve with JAICOV_INVERT_REDUCED returns in the exterior-orientation entries of dx
+                                      what the reference's last pass leaves there in MatrixInversion.REDUCED -- the UNSOLVED
+                                      right-hand side scaled twice by the preconditioner, V_c^2 n_c (BA:261-267 solve only the
+                                      leading numRows, BA:273 scales all of dx; BA:430, 450-461 then use these entries for Omega
+                                      and the update) -- instead of the back-substituted step.  Default 0.      */
+    int32_t  reserved[7];
 } jaicov_engine_options;
 
 typedef struct jaicov_engine jaicov_engine;

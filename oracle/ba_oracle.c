@@ -1123,6 +1123,28 @@ int oracle_dsptri(int n, double *ap, const int *ipiv, double *work) {
 }
 #undef AP
 
+/* r = b - A x for symmetric packed 'U' A, accumulated in long double (x87 extended: 64-bit mantissa) and rounded once:
+ * the residual of extended-precision iterative refinement.  NOT part of the reference's algorithm: tests/golden/make_cfg4_truth.py
+ * uses it to obtain the exact solution of the oracle's own system, against which the oracle's (dspsv) and the GPU's
+ * (Cholesky) forward errors are both measured at cond(N) ~ 1e9. */
+void oracle_residual_ld(int n, const double *ap, const double *x, const double *b, double *r) {
+    long double *acc = (long double *)malloc(sizeof(long double) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) acc[i] = (long double)b[i];
+    size_t kk = 0;
+    for (int j = 0; j < n; j++) {
+        long double xj = (long double)x[j], t = 0.0L;
+        for (int i = 0; i < j; i++) {
+            long double a = (long double)ap[kk + i];
+            acc[i] -= a * xj;
+            t += a * (long double)x[i];
+        }
+        acc[j] -= t + (long double)ap[kk + j] * xj;
+        kk += (size_t)j + 1;
+    }
+    for (int i = 0; i < n; i++) r[i] = (double)acc[i];
+    free(acc);
+}
+
 /* MX:338-366: returns 0, >0 singular (MatrixSingularException), <0 illegal argument */
 int oracle_solve(int U, double *N, double *n, int invert) {
     int *ipiv = (int *)malloc(sizeof(int) * (U > 0 ? U : 1));
@@ -1167,8 +1189,181 @@ double oracle_update(const jaicov_problem_desc *d, double *vals, const double *d
 }
 
 /* ============================================================================================================
- * a16/a17: estimateModel loop (BA:203-387) + updateModel (BA:389-442), FULL / NONE inversion modes.
- * Centroiding (BA:115-201) is the caller's business (host logic); vals are updated in place.
+ * a18: centroidCoordinates (BA:115-201).  "Unknown parameters" are the parameters registered by addUnknownParameter
+ * (BA:645-650), i.e. those that own a column.  The mean of all unknown X (object AND camera), Y, Z is subtracted
+ * (invert == 0; needs equal, non-zero counts: BA:142-151) or added back (invert != 0) to those parameters and to the
+ * OBSERVED values of every directly observed coordinate (BA:179-200, whatever the state of the referenced parameter).
+ * centroid[3] is output for invert == 0 and input otherwise.  Returns 0, or JAICOV_ERR_UNSUPPORTED for the
+ * UnsupportedOperationException of BA:151.
+ * ============================================================================================================ */
+static int slot_axis(const jaicov_problem_desc *d, int slot) {
+    if (slot < 3 * d->n_points) return slot % 3;                        /* OBJECT_COORDINATE_X/Y/Z */
+    int e0 = slot_eo(d, 0);
+    if (slot >= e0) { int k = (slot - e0) % 6; return k < 3 ? k : -1; }   /* CAMERA_COORDINATE_X/Y/Z */
+    return -1;
+}
+int oracle_centroid(const jaicov_problem_desc *d, double *vals, double *dg_obs, int invert, double centroid[3]) {
+    int ns = oracle_num_slots(d);
+    int32_t *sc = (int32_t *)malloc(sizeof(int32_t) * ns);
+    oracle_slot_columns(d, sc);
+    if (!invert) {
+        double x0 = 0, y0 = 0, z0 = 0;
+        int cntX = 0, cntY = 0, cntZ = 0;
+        /* unknownParameters is a LinkedHashSet in registration order (BA:667-782): points in first-seen order, ... the sum is
+         * taken in slot order here; the order only moves the last bits of the mean */
+        for (int s = 0; s < ns; s++) {
+            if (sc[s] < 0) continue;
+            switch (slot_axis(d, s)) {
+                case 0: x0 += vals[s]; cntX++; break;
+                case 1: y0 += vals[s]; cntY++; break;
+                case 2: z0 += vals[s]; cntZ++; break;
+                default: break;
+            }
+        }
+        if (cntX == cntY && cntX == cntZ && cntY == cntZ && cntX > 0) {
+            centroid[0] = x0 / cntX; centroid[1] = y0 / cntY; centroid[2] = z0 / cntZ;
+        } else { free(sc); return JAICOV_ERR_UNSUPPORTED; }
+    }
+    double sign = invert ? 1.0 : -1.0;
+    double c[3] = {sign * centroid[0], sign * centroid[1], sign * centroid[2]};
+    for (int s = 0; s < ns; s++) {
+        int a = slot_axis(d, s);
+        if (sc[s] >= 0 && a >= 0) vals[s] = vals[s] + c[a];
+    }
+    for (int r = 0; r < d->n_direct_rows; r++) {
+        int a = slot_axis(d, d->dg_slot[r]);
+        if (a >= 0) dg_obs[r] = dg_obs[r] + c[a];
+    }
+    free(sc);
+    return 0;
+}
+
+/* ============================================================================================================
+ * f1: MatrixInversion.REDUCED / PRE_ELIMINATION.  reduceNormalEquationSystem (BA:1197-1342) image by image, literally:
+ * N22 = the image's EO block, inverted with MX.inv (dpptrf + dpptri); for every parameter of the image's interior
+ * orientation / distortion and of the object points it observes: n1 -= N12 inv(N22) n2, N11 -= N12 inv(N22) N21 (upper
+ * part through pk_add: MTJ's add is a no-op below the diagonal).  pre_elimination != 0 additionally parks inv(N22)
+ * and inv(N22) n2 in the EO rows of N and n for extractReducedParameters (BA:1258-1295).  N, n are the PRECONDITIONED
+ * system (BA:238 runs first).  Returns 0 or the LAPACK info of a failed MX.inv.
+ * ============================================================================================================ */
+static int image_unknowns(const jaicov_problem_desc *d, int img, int32_t *out) {
+    /* unknownInteriorOrientationAndDistortionParameters, then X, Y, Z of the object point of every image coordinate of the
+     * image in the image's order (BA:1297-1308); a point observed twice by one image appears twice, as in the reference */
+    int cam = d->image_camera[img], k = 0;
+    for (int t = 0; t < 3; t++)
+        if (d->io_col[3 * cam + t] >= 0) out[k++] = d->io_col[3 * cam + t];
+    for (int j = d->cam_dist_begin[cam]; j < d->cam_dist_begin[cam + 1]; j++)
+        if (d->dist_col[j] >= 0) out[k++] = d->dist_col[j];
+    for (int ip = 0; ip < d->n_image_points; ip++) {
+        if (d->ip_image[ip] != img) continue;
+        for (int t = 0; t < 3; t++) {
+            int c = d->point_col[3 * d->ip_point[ip] + t];
+            if (c >= 0) out[k++] = c;
+        }
+    }
+    return k;
+}
+int oracle_reduce(const jaicov_problem_desc *d, double *N, double *n, int pre_elimination) {
+    int32_t *up = (int32_t *)malloc(sizeof(int32_t) * (size_t)(3 + d->n_dist + 3 * d->n_image_points + 8));
+    for (int cam = 0; cam < d->n_cameras; cam++)                       /* BA:1198: cameras, then the camera's images */
+        for (int img = 0; img < d->n_images; img++) {
+            if (d->image_camera[img] != cam) continue;
+            int eo[6], m = 0;
+            for (int t = 0; t < 6; t++)
+                if (d->eo_col[6 * img + t] >= 0) eo[m++] = d->eo_col[6 * img + t];
+            double N22[21], n2[6];
+            for (int r = 0; r < m; r++) {
+                for (int c = r; c < m; c++) N22[pidx(r, c)] = pk_get(N, eo[r], eo[c]);
+                n2[r] = n[eo[r]];
+                if (pre_elimination) n[eo[r]] = 0;
+            }
+            int info = oracle_dpptrf(m, N22);
+            if (!info) info = oracle_dpptri(m, N22);
+            if (info) { free(up); return info; }
+            if (pre_elimination)
+                for (int r = 0; r < m; r++) {
+                    double nr = n2[r], dv = N22[pidx(r, r)];
+                    pk_set(N, eo[r], eo[r], dv);
+                    n[eo[r]] += dv * nr;
+                    for (int c = r + 1; c < m; c++) {
+                        double nc = n2[c], ov = N22[pidx(r, c)];
+                        pk_set(N, eo[r], eo[c], ov);
+                        n[eo[r]] += ov * nc;
+                        n[eo[c]] += ov * nr;
+                    }
+                }
+            int k = image_unknowns(d, img, up);
+            for (int a = 0; a < k; a++) {
+                int rowN = up[a];
+                double n12[6];
+                for (int c = 0; c < m; c++) {
+                    double dot = 0;
+                    for (int r = 0; r < m; r++) dot += pk_get(N, rowN, eo[r]) * (r <= c ? N22[pidx(r, c)] : N22[pidx(c, r)]);
+                    n12[c] = dot;
+                }
+                double nd = 0;
+                for (int c = 0; c < m; c++) nd += n12[c] * n2[c];
+                n[rowN] += -nd;
+                for (int b = 0; b < k; b++) {
+                    int colN = up[b];
+                    double dot = 0;
+                    for (int r = 0; r < m; r++) dot += n12[r] * pk_get(N, colN, eo[r]);
+                    pk_add(N, rowN, colN, -dot);
+                }
+            }
+        }
+    free(up);
+    return 0;
+}
+
+/* extractReducedParameters (BA:1344-1453): dx2 = inv(N22) n2 - inv(N22) N21 dx1 from what oracle_reduce parked */
+void oracle_extract_reduced(const jaicov_problem_desc *d, const double *N, double *n) {
+    int32_t *up = (int32_t *)malloc(sizeof(int32_t) * (size_t)(3 + d->n_dist + 3 * d->n_image_points + 8));
+    for (int cam = 0; cam < d->n_cameras; cam++)
+        for (int img = 0; img < d->n_images; img++) {
+            if (d->image_camera[img] != cam) continue;
+            int eo[6], m = 0;
+            for (int t = 0; t < 6; t++)
+                if (d->eo_col[6 * img + t] >= 0) eo[m++] = d->eo_col[6 * img + t];
+            double inv[21], dx2[6];
+            for (int r = 0; r < m; r++) {
+                for (int c = r; c < m; c++) inv[pidx(r, c)] = pk_get(N, eo[r], eo[c]);
+                dx2[r] = n[eo[r]];
+            }
+            int k = image_unknowns(d, img, up);
+            for (int a = 0; a < k; a++) {
+                int rowN = up[a];
+                double n21[6] = {0, 0, 0, 0, 0, 0};
+                for (int r = 0; r < m; r++) {
+                    double vr = pk_get(N, rowN, eo[r]);
+                    n21[r] += inv[pidx(r, r)] * vr;
+                    for (int c = r + 1; c < m; c++) {
+                        double vc = pk_get(N, rowN, eo[c]), irc = inv[pidx(r, c)];
+                        n21[r] += irc * vc;
+                        n21[c] += irc * vr;
+                    }
+                }
+                for (int r = 0; r < m; r++) dx2[r] += -n[rowN] * n21[r];
+            }
+            for (int r = 0; r < m; r++) n[eo[r]] = dx2[r];
+        }
+    free(up);
+}
+
+/* numRows of BA:262 / BA:284 */
+int oracle_reduced_rows(const jaicov_problem_desc *d) {
+    int k = d->rank_defect + 3 * d->n_points;      /* objectCoordinates.size() * 3: ALL object points (quirk Q5) */
+    for (int i = 0; i < 3 * d->n_cameras; i++) k += d->io_col[i] >= 0;
+    for (int i = 0; i < d->n_dist; i++) k += d->dist_col[i] >= 0;
+    return k;
+}
+
+/* ============================================================================================================
+ * a16/a17: estimateModel loop (BA:203-387) + updateModel (BA:389-442).  invert = MatrixInversion (BA:65-70):
+ * 0 NONE, 1 FULL, 2 REDUCED, 3 PRE_ELIMINATION (BA:261-271, 283-294) -- literally, including what REDUCED leaves in the
+ * exterior-orientation entries of dx in the last pass.
+ * Centroiding (BA:115-201) is oracle_centroid, called by the caller around this loop as BA:224-225 / 357-358 do; vals are
+ * updated in place.
  * Q_out (packed, may be NULL) receives Qxx when invert != 0.
  * ============================================================================================================ */
 typedef struct {
@@ -1211,10 +1406,25 @@ int oracle_estimate(const jaicov_problem_desc *d, double *vals, double sigma2apr
         oracle_precondition(U, V, N, n);                       /* BA:238 */
         complete = isEstimated;
         int want_inv = complete && invert;
-        info = oracle_solve(U, N, n, want_inv);                /* BA:270 / BA:294 */
-        if (info) { state = -2; break; }
-        oracle_precondition(U, V, want_inv ? N : NULL, n);     /* BA:273 / BA:297 */
-        if (complete && Q_out && invert) memcpy(Q_out, N, sizeof(double) * plen);
+        if (complete) {                                        /* BA:252-280 */
+            if (invert == 2 || invert == 3) {
+                info = oracle_reduce(d, N, n, invert == 3);    /* BA:264 */
+                if (!info) info = oracle_solve(oracle_reduced_rows(d), N, n, 1);   /* BA:266: leading numRows only */
+            } else
+                info = oracle_solve(U, N, n, invert == 1);     /* BA:270 */
+            if (info) { state = -2; break; }
+            oracle_precondition(U, V, N, n);                   /* BA:273: N too, whatever the mode */
+        } else {
+            if (invert == 3) {                                 /* BA:283-291 */
+                info = oracle_reduce(d, N, n, 1);
+                if (!info) info = oracle_solve(oracle_reduced_rows(d), N, n, 0);
+                if (!info) oracle_extract_reduced(d, N, n);
+            } else
+                info = oracle_solve(U, N, n, 0);               /* BA:294 */
+            if (info) { state = -2; break; }
+            oracle_precondition(U, V, NULL, n);                /* BA:297 */
+        }
+        if (complete && Q_out && want_inv) memcpy(Q_out, N, sizeof(double) * plen);
         double *dx = n;
         /* ---- updateModel (BA:389-442) ---- */
         int rejected = 0;

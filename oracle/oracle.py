@@ -63,6 +63,13 @@ def lib():
         L.oracle_update.restype = C.c_double
         L.oracle_estimate.argtypes = [P, _pd, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, _pd,
                                       C.POINTER(OracleResult)]
+        L.oracle_residual_ld.argtypes = [C.c_int, _pd, _pd, _pd, _pd]
+        L.oracle_residual_ld.restype = None
+        L.oracle_centroid.argtypes = [P, _pd, _pd, C.c_int, _pd]
+        L.oracle_reduce.argtypes = [P, _pd, _pd, C.c_int]
+        L.oracle_extract_reduced.argtypes = [P, _pd, _pd]
+        L.oracle_extract_reduced.restype = None
+        L.oracle_reduced_rows.argtypes = [P]
         L.oracle_faithful_image_points.argtypes = [P, _pd, C.c_double, C.c_int, C.c_int, _pd, _pd]
         L.oracle_faithful_image_points.restype = C.c_double
         L.oracle_block_weight.argtypes = [P, C.c_double, C.c_int, _pd]
@@ -149,6 +156,27 @@ class Oracle:
         v = _f(values).copy(); dx = _f(dx)
         mx = self.L.oracle_update(C.byref(self.desc), _p(v), _p(dx))
         return v, float(mx)
+
+    def centroid(self, values, dg_obs, invert=False, centroid=None):
+        """BundleAdjustment.centroidCoordinates (BA:115-201).  Returns (values, dg_obs, centroid) -- copies."""
+        v = _f(values).copy(); o = _f(dg_obs).copy()
+        c = np.zeros(3) if centroid is None else _f(centroid).copy()
+        rc = self.L.oracle_centroid(C.byref(self.desc), _p(v), _p(o) if o.size else C.cast(None, _pd), int(invert), _p(c))
+        if rc:
+            raise ArithmeticError(f"oracle_centroid: the numbers of coordinate components are un-equal or zero (rc={rc})")
+        return v, o, c
+
+    def reduce(self, N, n, pre_elimination=False):
+        """reduceNormalEquationSystem (BA:1197-1342), in place on the preconditioned system."""
+        info = self.L.oracle_reduce(C.byref(self.desc), _p(N), _p(n), int(pre_elimination))
+        if info:
+            raise ArithmeticError(f"oracle_reduce info={info}")
+
+    def extract_reduced(self, N, n):
+        self.L.oracle_extract_reduced(C.byref(self.desc), _p(N), _p(n))
+
+    def reduced_rows(self):
+        return int(self.L.oracle_reduced_rows(C.byref(self.desc)))
 
     def estimate(self, values=None, sigma2=None, lam0=0.0, max_iter=5000, invert=True, simulation=False):
         v = _f(self.fp.values if values is None else values).copy()

@@ -195,6 +195,42 @@ def test_simulation_leaves_parameters_and_gives_the_oracles_cofactors(oracle_mod
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_block"])
+def test_reduced_reference_quirk_option_reproduces_the_references_last_pass(oracle_mod, name):
+    """Engine option reduced_reference_quirk (BundleAdjustment.java:261-267, 273, 430, 450-461): a solve with
+    MatrixInversion.REDUCED leaves V_c^2 n_c in the exterior-orientation entries of dx, which the reference then uses for
+    Omega and the update.  Checked away from convergence (where the quirk is large) against the oracle's literal restatement,
+    on the EO-pre-eliminated path (tiny_block) and on the full-order path (tiny)."""
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    N, n, V = o.build(fp.values, s2)
+    o.precondition(V, N, n)
+    o.reduce(N, n, False)
+    k, U, d = o.reduced_rows(), fp.n_unknowns, fp.rank_defect
+    assert o.L.oracle_solve(k, oracle_mod._p(N), oracle_mod._p(n), 1) == 0
+    o.precondition(V, N, n)
+    dx_ref = n
+    eng = engine.Engine(fp, reduced_reference_quirk=True)
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_REDUCED)
+    eng.build(s2, 0.0)
+    dx = eng.solve(engine.INVERT_REDUCED)
+    np.testing.assert_allclose(dx[d:k], dx_ref[d:k], rtol=0, atol=1e-9 * np.abs(dx_ref[d:k]).max())
+    np.testing.assert_allclose(dx[k:], dx_ref[k:], rtol=1e-9, atol=1e-12 * np.abs(dx_ref[k:]).max())
+    om_ref = o.omega(fp.values, s2, dx_ref)
+    assert abs(eng.omega(s2, dx) - om_ref) <= 1e-9 * om_ref
+    # without the option the same call returns the solved step
+    eng2 = engine.Engine(fp)
+    eng2.set_parameters(fp.values)
+    eng2.prepare_inverse(engine.INVERT_REDUCED)
+    eng2.build(s2, 0.0)
+    dx2 = eng2.solve(engine.INVERT_REDUCED)
+    full, _, _, _ = o.step(fp.values, s2)
+    np.testing.assert_allclose(dx2[k:], full[k:], rtol=0, atol=1e-9 * np.abs(full[k:]).max())
+    eng.close(); eng2.close()
+
+
 def test_interrupt_ends_the_loop_with_state_interrupt():
     """BundleAdjustment.interrupt() (BundleAdjustment.java:1455, polled at :240 and :320) = jaicov_neq_cancel."""
     fp = scene.config("tiny")

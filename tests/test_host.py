@@ -756,3 +756,65 @@ def test_engine_reproduces_the_reports_residuals(H, example_report):
     finally:
         eng.close()
     _check_residuals(cam, lambda k: w[k], example_report)
+
+
+def _control_point_block(H, base, n_ctrl=5):
+    """The bundled block with a DirectlyObservedParameterGroup on the first n_ctrl object points (X, Y, Z each)."""
+    pr = H.read_aicon_flat(base)
+    ba = H.BundleAdjustment()
+    for cam in pr.cameras():
+        ba.add(cam)
+    obs = []
+    for p in pr.points()[:n_ctrl]:
+        for up in (p.getX(), p.getY(), p.getZ()):
+            o = H.ObservationParameter(up); o.setVariance(0.05 ** 2); obs.append(o)
+    grp = H.DirectlyObservedParameterGroup(obs)
+    ba.add(grp)
+    return pr, ba, obs
+
+
+def test_centroid_coordinates_match_the_oracle_restatement(H, example_base, oracle_mod):
+    """BundleAdjustment.centroidCoordinates (BundleAdjustment.java:115-201): host mirror vs the oracle's restatement on the same
+    flat problem, forward and back, to 1e-12 of the coordinate scale (north_star: 1e-9) -- parameters AND the observed values
+    of the directly observed coordinates (BA:179-200)."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr, ba, obs = _control_point_block(H, example_base)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba).validate()
+    assert fp.n_direct_rows == 15
+    o = oracle_mod.Oracle(fp)
+    vo, dgo, c = o.centroid(fp.values, fp.dg_obs)
+    ba.centroidCoordinates(False); ba.flatten()
+    f1 = flat_problem(ba)
+    scale = np.abs(fp.values[:3 * fp.n_points]).max()
+    assert np.abs(f1.values - vo).max() <= 1e-12 * scale
+    assert np.abs(f1.dg_obs - dgo).max() <= 1e-12 * scale
+    # the centroid is the mean over object AND camera coordinates that own a column (BA:119-139)
+    cols = fp.slot_columns()
+    s_eo = fp.slot_eo(0)
+    xs = np.concatenate([fp.values[0:3 * fp.n_points:3], fp.values[s_eo::6]])
+    assert np.all(cols[:3 * fp.n_points] >= 0) and abs(c[0] - xs.mean()) <= 1e-12 * scale
+    assert np.abs(f1.values[0:3 * fp.n_points:3].sum() + f1.values[s_eo::6].sum()) <= 1e-9 * scale   # centred
+    # interior orientation, angles and distortion are not shifted
+    np.testing.assert_array_equal(f1.values[3 * fp.n_points:s_eo], fp.values[3 * fp.n_points:s_eo])
+    np.testing.assert_array_equal(f1.values[s_eo + 3::6], fp.values[s_eo + 3::6])
+    # and back (BA:357-358)
+    vb, dgb, _ = o.centroid(vo, dgo, True, c)
+    ba.centroidCoordinates(True); ba.flatten()
+    f2 = flat_problem(ba)
+    assert np.abs(f2.values - vb).max() <= 1e-12 * scale and np.abs(f2.dg_obs - dgb).max() <= 1e-12 * scale
+    assert np.abs(f2.values - fp.values).max() <= 1e-12 * scale
+
+
+def test_centroid_needs_equal_component_counts(H, example_base, oracle_mod):
+    """BA:142-151: a fixed coordinate component (it is not an unknown parameter, BA:645-650) makes the counts unequal ->
+    UnsupportedOperationException in the reference, an error in both restatements."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    pr, ba, obs = _control_point_block(H, example_base)
+    pr.points()[20].getY().setColumn(H.COLUMN_FIXED)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba).validate()
+    with pytest.raises(ArithmeticError):
+        oracle_mod.Oracle(fp).centroid(fp.values, fp.dg_obs)
+    with pytest.raises(Exception):
+        ba.centroidCoordinates(False)

@@ -238,3 +238,45 @@ def test_sharded_accumulation_adds_up(oracle_mod):
     N1, n1 = o.accumulate(fp.values, fp.sigma2apriori, h, fp.n_images, False)
     np.testing.assert_allclose(N0 + N1, N, rtol=1e-12, atol=1e-14 * np.abs(N).max())
     np.testing.assert_allclose(n0 + n1, n, rtol=1e-12, atol=1e-14 * np.abs(n).max())
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
+def test_reduced_and_pre_elimination_restatements_agree_with_full(oracle_mod, name):
+    """MatrixInversion.REDUCED / PRE_ELIMINATION (BundleAdjustment.java:261-267, 283-291, 1197-1453) restated literally
+    (reduceNormalEquationSystem, solve on the leading numRows, extractReducedParameters): same iteration count, same
+    adjusted parameters, same Omega and the same leading numRows x numRows block of Qxx as MatrixInversion.FULL."""
+    from bundle_adjustment_amd import scene
+    from bundle_adjustment_amd.problem import packed_to_full
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    v1, Q1, r1 = o.estimate(invert=1)
+    k, U = o.reduced_rows(), fp.n_unknowns
+    assert k == fp.rank_defect + 3 * fp.n_points + int((fp.io_col >= 0).sum() + (fp.dist_col >= 0).sum()) == int(fp.eo_col.min())
+    Qf = packed_to_full(Q1, U)[:k, :k]
+    for mode in (2, 3):
+        v, Q, r = o.estimate(invert=mode)
+        assert r.state == 1 and r.iterations == r1.iterations
+        assert (np.abs(v - v1) / np.maximum(np.abs(v1), 1e-3)).max() < 1e-10
+        assert abs(r.omega - r1.omega) <= 1e-10 * r1.omega
+        Qm = packed_to_full(Q, U)[:k, :k]
+        assert np.abs(Qm - Qf).max() <= 1e-9 * np.abs(Qf).max()
+
+
+def test_reduced_mode_leaves_the_unsolved_rhs_in_the_eo_step(oracle_mod):
+    """in the last pass of MatrixInversion.REDUCED the exterior-orientation entries of dx are V_c^2 n_c
+    (the unsolved, twice-scaled right-hand side), not the solved step."""
+    from bundle_adjustment_amd import scene
+    fp = scene.config("tiny_block")
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    N, n, V = o.build(fp.values, s2)
+    n0 = n.copy()
+    o.precondition(V, N, n)
+    o.reduce(N, n, False)
+    k = o.reduced_rows()
+    assert o.L.oracle_solve(k, oracle_mod._p(N), oracle_mod._p(n), 1) == 0
+    o.precondition(V, N, n)
+    np.testing.assert_allclose(n[k:], V[k:] ** 2 * n0[k:], rtol=1e-15)
+    dx_full, _, _, _ = o.step(fp.values, s2)
+    np.testing.assert_allclose(n[:k], dx_full[:k], rtol=0, atol=1e-9 * np.abs(dx_full[:k]).max())
+    assert np.abs(n[k:] - dx_full[k:]).max() > 1e-3 * np.abs(dx_full[k:]).max()      # far from the solution away from convergence
