@@ -240,15 +240,15 @@ def main():
                          "algorithmic_flops_per_launch": ks["flops"] / max(ks["launches"], 1)},
         }
         # second roofline, for the HBM-bound half of the pass: algorithmic bytes of the structure-aware assembly (DESIGN.md
-        # section 4) over its measured stage time.  Per dense image group of m rows: D^-1 read for T = D^-1 [A | w] (8 m^2),
-        # lower triangle of D^-1 read and of P' written by the EO elimination, lower triangle of P' read by the point x
-        # point gather (3 x 4 m^2); the lower triangle of the reduced N written once (the gather stores its strips) and read once
-        # by the copy into the solver (2 x 4 e0^2);
-        # Jacobian rows written and read once (2 x 0.42 kB per image point).
+        # section 4) over its measured stage time.  Per dense image group of m rows: D^-1 read in full for T = D^-1 [A_c | w]
+        # (8 m^2) and its lower triangle once more by the point x point gather, which forms the EO-eliminated weights
+        # P' = sigma2 D^-1 - U U' on the fly (4 m^2; nothing of P' is written or read back any more); the lower triangle of the
+        # reduced N written once by the gather (4 e0^2; the factorisation reads N itself: no scaled copy); Jacobian rows written
+        # and read once (2 x 0.42 kB per image point).
         if fp.n_image_blocks and world == 1:
             m2 = float(np.sum((2.0 * np.diff(fp.blk_ip_begin)) ** 2))
             e0 = eng.reduced_order()
-            abytes = 8.0 * m2 + 12.0 * m2 + 8.0 * float(e0) ** 2 + 2.0 * 420.0 * fp.n_image_points
+            abytes = 8.0 * m2 + 4.0 * m2 + 4.0 * float(e0) ** 2 + 2.0 * 420.0 * fp.n_image_points
             asm_ms = stage.get("assembly", 0.0) / a.steps
             out["assembly_roofline"] = {"bound": "hbm", "achieved": abytes / (asm_ms * 1e-3) / 1e9 if asm_ms > 0 else 0.0,
                                         "peak": 8000.0, "unit": "GB/s", "frac": abytes / (asm_ms * 1e-3) / 1e9 / 8000.0 if asm_ms > 0 else 0.0,

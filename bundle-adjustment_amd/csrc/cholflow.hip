@@ -76,6 +76,7 @@ struct FlowArgs {
     const double *V;         // [>= 128 nb]
     const double *Bh;        // [d][bstride]
     int d, U, bstride;
+    double *diag_scratch;    // INLINE_DIAG: [grid][128 x DP + 8 x 16 x WDP] work arrays of potrf_diag_body in global memory
     const double *zeros;     // 64 zeros
     double *scratch;         // [grid][128 x 128] per workgroup: operand of the multiplication by inv(L_jj)'
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
@@ -114,7 +115,17 @@ __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int PF>   // PF = k-steps the operand loads run ahead of the MFMAs (1 or 2)
+// a real call: the diagonal block's register appetite (potrf_diag.h wants all 512) must not reach the tile loop's allocation
+__device__ __attribute__((noinline)) void flow_inline_diag(double *A, long ld, double *inv_out, int *info, int blk, double *ws) {
+    potrf_diag_body(A, ld, inv_out, info, blk, 0, ws, ws + 128 * DP);
+}
+
+// PF = k-steps the operand loads run ahead of the MFMAs (1 or 2).  INLINE_DIAG: no diagonal kernel beside this one -- the
+// workgroup that finishes the updates of a diagonal tile factors and inverts it itself, with the work arrays of potrf_diag.h in
+// global memory instead of 150 KB of LDS (several times slower per block: the chain then bounds the whole factorisation).  For
+// hosts on which two kernels cannot run at the same time (rocprofv3 --pmc serialises every dispatch; AMD_SERIALIZE_KERNEL): the
+// factorisation stays correct there, and the tile kernel's HBM counters can be collected at all.
+template <int PF, bool INLINE_DIAG>
 __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
     __shared__ double smem[2 * FLOW_STAGE];
     __shared__ int s_msg[4];
@@ -369,6 +380,25 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             drain_stores();
             if (to_scratch) continue;     // phase 1 follows (its wait comes with a barrier)
             __syncthreads();
+            if (INLINE_DIAG && phase == 0 && fin) {
+                // the updated diagonal tile is in memory (written through): factor + invert it here, work arrays in this
+                // workgroup's global scratch; plain stores, published behind an agent-scope release like the diagonal kernel's
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    drain_stores();
+                }
+                __syncthreads();
+                double *ws = g.diag_scratch + (long)blockIdx.x * (128 * DP + 8 * 16 * WDP);
+                flow_inline_diag(g.L + (long)tj * 128 * g.ld + (long)tj * 128, g.ld, g.invd + (long)tj * 16384, g.info, tj, ws);
+                drain_stores();
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    drain_stores();
+                    flow_st(g.done + (long)tj * g.fs + tj, 1);
+                }
+                break;
+            }
             if (tid == 0) {
                 if (phase == 1) flow_st(g.done + (long)ti * g.fs + tj, 1);                 // L[i][j] is final
                 else if (fin) flow_st(g.diag_ready + tj, 1);                               // updated diagonal tile, for the diagonal kernel
@@ -439,6 +469,41 @@ static std::vector<int4> flow_schedule(int nb, int row_blocks, int w) {
     return tasks;
 }
 
+// Can two kernels of this process run at the same time?  Probed once: a kernel that waits (at most 50 ms) for a word that a
+// second kernel on another stream sets.  Under rocprofv3 --pmc (every dispatch serialised) the second one only starts after
+// the first has given up.
+__global__ void flow_probe_wait_kernel(int *word, int *result) {
+    const long long t0 = wall_clock64();
+    int seen = 0;
+    while (wall_clock64() - t0 < 5000000LL) {
+        if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+        __builtin_amdgcn_s_sleep(20);
+    }
+    *result = seen;
+}
+__global__ void flow_probe_set_kernel(int *word) { __hip_atomic_store(word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+bool DenseSolver::flow_kernels_overlap() {
+    static int cached = -1;
+    if (cached >= 0) return cached != 0;
+    if (getenv("JAICOV_FLOW_INLINE_DIAG")) return (cached = 0) != 0;      // force the one-kernel form
+    int *d = nullptr, h[2] = {0, 0};
+    hipStream_t s2 = nullptr;
+    bool ok = hipMalloc(&d, 2 * sizeof(int)) == hipSuccess && hipMemset(d, 0, 2 * sizeof(int)) == hipSuccess &&
+              hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(flow_probe_wait_kernel, dim3(1), dim3(1), 0, dstream, d, d + 1);
+        hipLaunchKernelGGL(flow_probe_set_kernel, dim3(1), dim3(1), 0, s2, d);
+        ok = hipStreamSynchronize(dstream) == hipSuccess && hipStreamSynchronize(s2) == hipSuccess &&
+             hipMemcpy(h, d, 2 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (s2) hipStreamDestroy(s2);
+    if (d) hipFree(d);
+    cached = ok && h[1] == 1 ? 1 : 0;
+    if (!cached && getenv("JAICOV_VERBOSE")) fprintf(stderr, "jaicov: kernels do not overlap on this host: dataflow factorisation runs as one kernel with inline diagonal blocks\n");
+    return cached != 0;
+}
+
 hipError_t DenseSolver::flow_init() {
     const int nb = nfact / 128, row_blocks = n / 128;
     if (!dstream) return hipErrorNotSupported;
@@ -476,6 +541,8 @@ void DenseSolver::flow_release() {
     if (flow_flags) hipFree(flow_flags);
     if (flow_scratch) hipFree(flow_scratch);
     if (flow_trace) hipFree(flow_trace);
+    if (flow_diag_scratch) hipFree(flow_diag_scratch);
+    flow_diag_scratch = nullptr;
     if (flow_alive) hipHostFree(flow_alive);
     flow_alive = nullptr;
     for (hipEvent_t e : {flow_e0, flow_e1, flow_e2, flow_e3, flow_t0, flow_t1})
@@ -507,6 +574,22 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.seq = ++flow_seq;
     HIPCHK(hipMemsetAsync(flow_flags, 0, flow_words * sizeof(int), stream));
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
+    static const int pf = getenv("JAICOV_FLOW_PF") ? atoi(getenv("JAICOV_FLOW_PF")) : 1;   // measured equal (22.7-23.0 ms at order 15104): one step of lead covers the latency
+    if (!flow_kernels_overlap()) {
+        // Kernels cannot run side by side here (every dispatch serialised: counter collection, a debugging environment): the
+        // diagonal kernel and the tile kernel would wait for each other until the time limit.  ONE kernel, diagonal blocks inline.
+        if (!flow_diag_scratch) HIPCHK(hipMalloc(&flow_diag_scratch, (size_t)flow_grid * (128 * DP + 8 * 16 * WDP) * sizeof(double)));
+        g.diag_scratch = flow_diag_scratch;
+        g.alive = nullptr;
+        if (all_ready) HIPCHK(hipStreamWaitEvent(stream, all_ready, 0));
+        if (profile) HIPCHK(hipEventRecord(flow_t0, stream));
+        hipLaunchKernelGGL((chol_tile_kernel<1, true>), dim3(flow_grid), dim3(256), 0, stream, g);
+        if (profile) {
+            HIPCHK(hipEventRecord(flow_t1, stream));
+            flow_timed = true;
+        }
+        return hipGetLastError();
+    }
     HIPCHK(hipEventRecord(flow_e0, stream));
     HIPCHK(hipStreamWaitEvent(dstream, flow_e0, 0));
     if (all_ready) HIPCHK(hipStreamWaitEvent(dstream, all_ready, 0));
@@ -527,9 +610,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
         }
     }
     if (profile) HIPCHK(hipEventRecord(flow_t0, stream));
-    static const int pf = getenv("JAICOV_FLOW_PF") ? atoi(getenv("JAICOV_FLOW_PF")) : 1;   // measured equal (22.7-23.0 ms at order 15104): one step of lead covers the latency
-    if (pf == 1) hipLaunchKernelGGL(chol_tile_kernel<1>, dim3(flow_grid), dim3(256), 0, stream, g);
-    else hipLaunchKernelGGL(chol_tile_kernel<2>, dim3(flow_grid), dim3(256), 0, stream, g);
+    if (pf == 2) hipLaunchKernelGGL((chol_tile_kernel<2, false>), dim3(flow_grid), dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL((chol_tile_kernel<1, false>), dim3(flow_grid), dim3(256), 0, stream, g);
     if (profile) {
         HIPCHK(hipEventRecord(flow_t1, stream));
         flow_timed = true;

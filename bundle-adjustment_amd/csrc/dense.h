@@ -59,6 +59,8 @@ struct DenseSolver {
     size_t flow_words = 0;
     double *flow_scratch = nullptr;
     long long *flow_trace = nullptr;
+    double *flow_diag_scratch = nullptr; // one-kernel form (kernels cannot overlap on this host): work arrays of the inline diagonal blocks
+    bool flow_kernels_overlap();         // probed once per process
     int *flow_alive = nullptr;           // host-visible: sequence number of the last diagonal kernel that has started
     int flow_seq = 0;
     hipEvent_t flow_e0 = nullptr, flow_e1 = nullptr, flow_e2 = nullptr, flow_e3 = nullptr, flow_t0 = nullptr, flow_t1 = nullptr;

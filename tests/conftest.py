@@ -25,3 +25,10 @@ def oracle_mod():
     import oracle
     oracle.build()
     return oracle
+
+
+@pytest.fixture(scope="session")
+def cfg4_scene():
+    """BASELINE config 4/5 (500 images x 5000 points, U = 18 014): built once per session (about 15 s)."""
+    from bundle_adjustment_amd import scene
+    return scene.config("cfg4")

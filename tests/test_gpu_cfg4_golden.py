@@ -1,0 +1,170 @@
+"""The HIP paths against the CPU oracle AT THE HEADLINE SIZE (BASELINE config 4/5: 500 images x 5000 points, U = 18 014).
+
+Fixture: tests/golden/cfg4/cfg4_oracle.npz (+ .json), written by tests/golden/make_cfg4_golden.py -- the oracle run once in
+full (66 min on one core): an intermediate pass at the start values and the final pass (dspsv + dsptri, MathExtension.java:
+338-366) at the updated values: dx, n, the probe N.v, Omega, diag Qxx, a 400 x 400 sample of Qxx, Qxx.v, ||Qxx||_F.
+
+What can agree how well.  The Jacobi-scaled normal matrix has cond ~ 1e9.  scripts/cfg4_decompose.py (run on the GPU box, numbers
+in DESIGN.md section 2) separates the causes of a difference in dx, all relative to max|dx|:
+  * the two assemblies round differently (n: 3e-12, N.v: 3e-11, below): the EXACT solutions of the GPU's and of the oracle's system
+    already differ by 2.2e-8 -- the floor for any comparison of a single step at this size, whatever the solver;
+  * solver on its own system against its exact solution (extended-precision refinement): oracle's packed Bunch-Kaufman 2.3e-9 ..
+    3.6e-9, GPU Cholesky of the EO-reduced system 2.6e-8, GPU Cholesky at full order 1.6e-7.
+The converged ESTIMATES, which is what north_star's 1e-9 speaks about, do not inherit the per-step figure: Newton's iteration
+corrects it (tests/test_gpu_fullsize.py: three device paths agree to 1e-12 after convergence).  The tolerances below are 3-5 x the
+achieved values, which are written next to them.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import engine
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    z = dict(np.load(os.path.join(G, "cfg4_oracle.npz")))
+    meta = json.load(open(os.path.join(G, "cfg4_oracle.json")))
+    z["probe"] = np.random.Generator(np.random.Philox(meta["probe_seed"])).standard_normal(meta["U"])
+    return z, meta
+
+
+@pytest.fixture(scope="module")
+def eng(cfg4_scene):
+    e = engine.Engine(cfg4_scene)
+    yield e
+    e.close()
+
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / np.abs(b).max())
+
+
+def packed_matvec(ap, v):
+    y = np.zeros(v.size); off = 0
+    for r in range(v.size):
+        row = ap[off:off + r + 1]
+        y[r] += row @ v[:r + 1]; y[:r] += row[:r] * v[r]
+        off += r + 1
+    return y
+
+
+def updated(fp, values, dx):
+    cols = fp.slot_columns(); v = values.copy(); m = cols >= 0
+    v[m] += dx[cols[m]]
+    return v
+
+
+def test_pass1_assembly_and_step(cfg4_scene, gold, eng):
+    fp = cfg4_scene
+    z, meta = gold
+    U, s2 = fp.n_unknowns, fp.sigma2apriori
+    assert (U, fp.n_observations) == (meta["U"], meta["n_observations"]) and s2 == meta["sigma2apriori"]
+    eng.set_parameters(fp.values)
+    # --- the product path: exterior orientations pre-eliminated, dataflow Cholesky of order 15 014
+    eng.prepare_inverse(engine.INVERT_NONE)
+    eng.build(s2, 0.0)
+    dx = eng.solve(False)
+    assert rel(dx, z["dx1"]) < 1e-7                                   # achieved 2.3e-8 (= the assembly-rounding floor 2.2e-8)
+    assert abs(eng.update(dx) - meta["max_abs_dx_pass1"]) < 1e-6 * meta["max_abs_dx_pass1"]
+    # --- the full system as the reference assembles it: N and n themselves
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_FULL)
+    eng.build(s2, 0.0)
+    N, n = eng.get_normal()
+    assert rel(n, z["n1"]) < 1e-10                                    # achieved 3.3e-12
+    Nv = packed_matvec(N, z["probe"])
+    assert rel(Nv, z["Nv1"]) < 1e-9                                   # achieved 2.7e-11
+    dxf = eng.solve(False)
+    assert rel(dxf, z["dx1"]) < 1e-6                                  # achieved 2.0e-7 (full-order Cholesky: 1.6e-7 on its own system)
+    # the step solves the system it was computed from: componentwise backward error
+    r = packed_matvec(N, dxf) - n
+    Na = np.abs(N)
+    assert np.abs(r).max() <= 2e-9 * (packed_matvec(Na, np.abs(dxf)) + np.abs(n)).max()
+    del N, Na
+
+
+def test_pass1_dense_contraction_mode(cfg4_scene, gold):
+    """assembly_mode = 1: J'WJ of the image groups as a dense contraction on the matrix cores (PDF:486-498 literally)."""
+    fp = cfg4_scene
+    z, _ = gold
+    de = engine.Engine(fp, assembly_mode=1)
+    de.set_parameters(fp.values)
+    de.build(fp.sigma2apriori, 0.0)
+    N, n = de.get_normal()
+    assert rel(n, z["n1"]) < 1e-10 and rel(packed_matvec(N, z["probe"]), z["Nv1"]) < 1e-9
+    del N
+    assert rel(de.solve(False), z["dx1"]) < 1e-6                      # achieved 1.9e-7
+    de.close()
+
+
+@pytest.mark.parametrize("mode", ["FULL", "REDUCED"])
+def test_final_pass_step_omega_and_cofactors(cfg4_scene, gold, eng, mode):
+    """The final pass (BA:252-280) at the parameters updated with the oracle's first step: dx, Omega, sigma0^2 and Qxx against
+    dspsv + dsptri at full order.  REDUCED: the inverse of the EO-reduced system against the leading block of that Qxx."""
+    fp = cfg4_scene
+    z, meta = gold
+    s2 = fp.sigma2apriori
+    inv = engine.INVERT_FULL if mode == "FULL" else engine.INVERT_REDUCED
+    eng.set_parameters(updated(fp, fp.values, z["dx1"]))
+    eng.prepare_inverse(inv)
+    eng.build(s2, 0.0)
+    dx2 = eng.solve(inv)
+    assert rel(dx2, z["dx2"]) < (1e-6 if mode == "FULL" else 1e-7)    # achieved 1.2e-7 / 1.4e-8
+    om = eng.omega(s2, dx2)
+    assert abs(om - meta["omega"]) <= 1e-11 * meta["omega"]           # achieved 1e-15 / 1e-13
+    assert abs(abs(om / fp.degree_of_freedom) - meta["sigma2aposteriori"]) <= 1e-11 * meta["sigma2aposteriori"]
+    k = eng.cofactor_order()
+    assert k == (fp.n_unknowns if mode == "FULL" else fp.n_unknowns - 6 * fp.n_images)
+    cols = z["sample_cols"]
+    keep = cols < k
+    Qs = eng.get_cofactor_sub(cols[keep].astype(np.int32))
+    ref = z["Qsample"][np.ix_(keep, keep)]
+    sd = np.sqrt(np.abs(np.diag(ref)))
+    assert np.abs((Qs - ref) / np.outer(sd, sd)).max() < 2e-6         # achieved 4.0e-7 / 1.5e-7 (correlation-scaled)
+    Q = eng.get_cofactor()
+    idx = np.arange(k, dtype=np.int64)
+    dg = Q[idx * (idx + 3) // 2]
+    assert np.abs(dg / z["diagQ"][:k] - 1.0).max() < 2e-6             # achieved 4.1e-7 / 1.5e-7, every one of the 18 014 variances
+    if mode == "FULL":
+        fro = float(np.sqrt(2.0 * np.dot(Q, Q) - np.dot(dg, dg)))
+        assert abs(fro - meta["qxx_frobenius"]) < 1e-6 * meta["qxx_frobenius"]     # achieved 1.1e-7
+        assert rel(packed_matvec(Q, z["probe"]), z["Qv"]) < 2e-6                   # achieved 3.5e-7
+    del Q
+
+
+def test_forward_errors_against_the_exact_solution(cfg4_scene, gold, eng):
+    """tests/golden/cfg4/cfg4_truth.npz: the oracle's solutions refined with extended-precision residuals (exact to ~1e-11).  The
+    GPU is measured against the exact solution of the ORACLE's system, so its figure contains the assembly-rounding floor."""
+    path = os.path.join(G, "cfg4_truth.npz")
+    if not os.path.exists(path):
+        pytest.skip("cfg4_truth.npz not generated")
+    t = np.load(path)
+    fp = cfg4_scene
+    z, _ = gold
+    s2 = fp.sigma2apriori
+    assert float(t["dx1_oracle_err"][0]) < 1e-8                       # the reference algorithm itself: 2.3e-9
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_NONE)
+    eng.build(s2, 0.0)
+    dx = eng.solve(False)
+    assert rel(dx, t["dx1_true"]) < 1e-7                              # achieved 2.4e-8
+    if "Qcols_true" in t:
+        eng.set_parameters(updated(fp, fp.values, z["dx1"]))
+        eng.prepare_inverse(engine.INVERT_FULL)
+        eng.build(s2, 0.0)
+        eng.solve(engine.INVERT_FULL)
+        qc = t["qcols"].astype(np.int32)
+        U = fp.n_unknowns
+        allc = np.arange(U, dtype=np.int32)
+        for a, c in enumerate(qc[:4]):
+            sub = eng.get_cofactor_sub(np.concatenate([[c], z["sample_cols"].astype(np.int32)]))
+            col = sub[0, 1:]
+            ref = t["Qcols_true"][a][z["sample_cols"]]
+            assert np.abs(col - ref).max() < 2e-6 * np.abs(t["Qcols_true"][a]).max()
+        del allc

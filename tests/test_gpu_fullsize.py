@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(scope="module")
-def cfg4():
-    return scene.config("cfg4")
+def cfg4(cfg4_scene):
+    return cfg4_scene
 
 
 @pytest.fixture(scope="module")
