@@ -202,38 +202,82 @@ __global__ __launch_bounds__(T_NT) void blk_T_kernel(DevProblem p, const int32_t
     }
 }
 
-// B2: shared block S_cc = A_c' T_c, n_c = A_c' T_w  -> atomics (one workgroup per block)
+// B2: shared block S_cc = A_c' T_c, n_c = A_c' T_w.  Two launches, and no atomics: every image block deals its rows to
+// gridDim.y workgroups (one workgroup per image left 500 serial iterations on a quarter-filled chip) which store their partial
+// sums; blk_cc_reduce_kernel then adds them up in a FIXED order (block list order, then part order), so that the camera block of
+// N -- the entries every image contributes to -- is the same bit pattern in every run (memory-side fp64 atomics summed it in
+// arrival order).  partial: [block in list][part][CC_ENT] doubles.
+constexpr int CC_ENT = KC_MAX * (KC_MAX + 1);
 __global__ __launch_bounds__(256) void blk_cc_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
                                                      const double *__restrict__ rowsA, const double *__restrict__ T,
-                                                     double sigma2, double *__restrict__ N, double *__restrict__ n,
-                                                     int schur) {
-    __shared__ int cols[KC_MAX];
+                                                     double sigma2, double *__restrict__ partial, int schur) {
     const int g = blk_list[blockIdx.x];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
     const long S = p.n_ip;
     const int img = p.ip_image[ipb], cam = p.image_camera[img];
-    const int jb = p.cam_dist_begin[cam], kc = 9 + p.cam_dist_begin[cam + 1] - jb;
-    // schur: the EO columns (shared 3..8) are pre-eliminated (schur.hip) and do not enter the reduced system
-    if (threadIdx.x < kc)
-        cols[threadIdx.x] = (schur && threadIdx.x >= 3 && threadIdx.x < 9) ? -1 : shared_col(p, img, cam, jb, threadIdx.x);
-    __syncthreads();
+    const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
     const int nent = kc * (kc + 1);   // a in [0,kc), b in [0,kc] (b == kc -> n)
+    double *out = partial + ((long)blockIdx.x * gridDim.y + blockIdx.y) * CC_ENT;
     for (int ent = threadIdx.x; ent < nent; ent += 256) {
         const int a = ent / (kc + 1), bb = ent - a * (kc + 1);
-        if (bb < kc && bb > a) continue;
-        const int ga = cols[a], gb = bb < kc ? cols[bb] : 0;
-        if (ga < 0 || gb < 0) continue;
-        const double *ra = rowsA + (long)(2 * shared_local(a)) * S + ipb;
-        const double *tb = T + (long)2 * ipb * KC_LD + bb;
+        // schur: the EO columns (shared 3..8) are pre-eliminated (schur.hip) and do not enter the reduced system
+        const bool skip = (bb < kc && bb > a) || (schur && ((a >= 3 && a < 9) || (bb >= 3 && bb < 9)));
         double s = 0.0;
-        // the rows of the block are dealt to gridDim.y workgroups (one workgroup per image left 500 serial iterations on
-        // a quarter-filled chip); the partial sums meet in the atomics below
-        const int o0 = (int)((long)(m / 2) * blockIdx.y / gridDim.y), o1 = (int)((long)(m / 2) * (blockIdx.y + 1) / gridDim.y);
-        for (int o = o0; o < o1; o++)
-            s += ra[o] * tb[(long)(2 * o) * KC_LD] + ra[S + o] * tb[(long)(2 * o + 1) * KC_LD];
-        s *= sigma2;
-        if (bb == kc) unsafeAtomicAdd(n + ga, s);
-        else nadd(N, p.ld, ga, gb, s);
+        if (!skip) {
+            const double *ra = rowsA + (long)(2 * shared_local(a)) * S + ipb;
+            const double *tb = T + (long)2 * ipb * KC_LD + bb;
+            const int o0 = (int)((long)(m / 2) * blockIdx.y / gridDim.y), o1 = (int)((long)(m / 2) * (blockIdx.y + 1) / gridDim.y);
+            for (int o = o0; o < o1; o++)
+                s += ra[o] * tb[(long)(2 * o) * KC_LD] + ra[S + o] * tb[(long)(2 * o + 1) * KC_LD];
+            s *= sigma2;
+        }
+        out[ent] = s;
+    }
+}
+
+// grid (CC_ENT, cameras), 256 threads: entry `ent` of camera `cam`.  Entries that involve an exterior-orientation column belong
+// to one image: the thread that visits that image's block adds its parts straight into N (sole owner).  The others are summed
+// over all blocks of the camera: thread t takes blocks t, t + 256, ... of the list, then a tree over the 256 partial sums.
+__global__ __launch_bounds__(256) void blk_cc_reduce_kernel(DevProblem p, const int32_t *__restrict__ blk_list, int n_list,
+                                                            int parts, const double *__restrict__ partial,
+                                                            double *__restrict__ N, double *__restrict__ n, int schur) {
+    __shared__ double red[256];
+    const int ent = blockIdx.x, cam = blockIdx.y, tid = threadIdx.x;
+    const int jb = p.cam_dist_begin[cam], kc = 9 + p.cam_dist_begin[cam + 1] - jb;
+    if (ent >= kc * (kc + 1)) return;
+    const int a = ent / (kc + 1), bb = ent - a * (kc + 1);
+    if (bb < kc && bb > a) return;
+    const bool eo = (a >= 3 && a < 9) || (bb >= 3 && bb < 9);
+    if (eo && schur) return;
+    double acc = 0.0;
+    for (int t = tid; t < n_list; t += 256) {
+        const int g = blk_list[t];
+        const int img = p.ip_image[p.blk_ip_begin[g]];
+        if (p.image_camera[img] != cam) continue;
+        double s = 0.0;
+        for (int q = 0; q < parts; q++) s += partial[((long)t * parts + q) * CC_ENT + ent];
+        if (eo) {
+            const int ga = shared_col(p, img, cam, jb, a), gb = bb < kc ? shared_col(p, img, cam, jb, bb) : 0;
+            if (ga >= 0 && gb >= 0) {
+                if (bb == kc) n[ga] += s;
+                else N[(long)max(ga, gb) * p.ld + min(ga, gb)] += s;
+            }
+        } else
+            acc += s;
+    }
+    if (eo) return;
+    red[tid] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (tid < w) red[tid] += red[tid + w];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int ga = shared_col(p, 0, cam, jb, a), gb = bb < kc ? shared_col(p, 0, cam, jb, bb) : 0;   // no EO column: the image is irrelevant
+        if (ga >= 0 && gb >= 0) {
+            if (bb == kc) n[ga] += red[0];
+            else N[(long)max(ga, gb) * p.ld + min(ga, gb)] += red[0];
+        }
     }
 }
 
@@ -422,7 +466,7 @@ __device__ __forceinline__ void pp_spread_row(double rowvec, double sigma2, doub
 
 template <bool FUSED>
 __device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const double (&ap)[6], const double (&up)[12], double sigma2,
-                                              double *strip, int c0, int cp0, int cp1, int cp2) {
+                                              double *strip, int c0, int cp0, int cp1, int cp2, int wlo = 0, int whi = PP_CW) {
     double p00 = d.P0.x, p01 = d.P0.y, p10 = d.P1.x, p11 = d.P1.y;
     if (FUSED) {
         p00 *= sigma2; p01 *= sigma2; p10 *= sigma2; p11 *= sigma2;
@@ -437,7 +481,7 @@ __device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const doub
 #pragma unroll
     for (int b = 0; b < 3; b++) {
         const int cq = d.cq[b];
-        if (cq < c0 || cq >= c0 + PP_CW) continue;
+        if (cq < c0 + wlo || cq >= c0 + whi) continue;      // [wlo, whi): the part of the strip this wave may touch
         const double g0 = p00 * d.aq[2 * b] + p01 * d.aq[2 * b + 1];
         const double g1 = p10 * d.aq[2 * b] + p11 * d.aq[2 * b + 1];
         if (cp0 >= cq) unsafeAtomicAdd(&strip[cq - c0], ap[0] * g0 + ap[1] * g1);
@@ -464,7 +508,7 @@ __device__ __forceinline__ int2 pp_range(const int2 *range, long idx) {
     return make_int2(__builtin_amdgcn_readfirstlane(g.x), __builtin_amdgcn_readfirstlane(g.y));
 }
 
-template <bool FUSED>
+template <bool FUSED, bool DET = false>
 __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             const double *__restrict__ Ubuf, double sigma2, double *__restrict__ N) {
     __shared__ double strip[3 * PP_CW];
@@ -479,31 +523,37 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     const int2 *range = reinterpret_cast<const int2 *>(pp.range);
     for (int i = tid; i < 3 * PP_CW; i += PP_NT) strip[i] = 0.0;
     __syncthreads();
-    if (ob + wave < oe) {
-        const int o0 = ob + wave;
+    // DET: every wave walks all images (step 1) with the ranges of ITS quarter of the strip's columns; else wave w takes every
+    // NW-th image with the ranges of the whole chunk
+    constexpr int STEP = DET ? 1 : NW;
+    const int2 *rng = DET ? reinterpret_cast<const int2 *>(pp.range_sub) : range;
+    const int nrc = DET ? 4 * nch : nch, rci = DET ? 4 * chunk + wave : chunk;
+    const int wlo = DET ? wave * (PP_CW / 4) : 0, whi = DET ? (wave + 1) * (PP_CW / 4) : PP_CW;
+    if (ob + (DET ? 0 : wave) < oe) {
+        const int o0 = ob + (DET ? 0 : wave);
         PPRecord r1 = pp_record(pp.recs, o0);
-        int2 g1 = pp_range(range, (long)o0 * nch + chunk);
-        const int o1 = min(o0 + NW, oe - 1);
+        int2 g1 = pp_range(rng, (long)o0 * nrc + rci);
+        const int o1 = min(o0 + STEP, oe - 1);
         PPRecord r2 = pp_record(pp.recs, o1);
-        int2 g2 = pp_range(range, (long)o1 * nch + chunk);
+        int2 g2 = pp_range(rng, (long)o1 * nrc + rci);
         PPData<FUSED> cur, nxt;
         double apc[6], upc[12];
         pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y);
         pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
-        for (int o = o0; o < oe; o += NW) {
-            const int o2 = min(o + 2 * NW, oe - 1);
+        for (int o = o0; o < oe; o += STEP) {
+            const int o2 = min(o + 2 * STEP, oe - 1);
             const PPRecord r3 = pp_record(pp.recs, o2);
-            const int2 g3 = pp_range(range, (long)o2 * nch + chunk);
+            const int2 g3 = pp_range(rng, (long)o2 * nrc + rci);
             double rown = 0.0;
-            if (o + NW < oe) {
+            if (o + STEP < oe) {
                 pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y);
                 rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
             }
-            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2);
+            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2, wlo, whi);
             // ranges longer than a wave: the remaining passes without prefetch (into the registers of `cur`, which is done)
             for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
                 pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y);
-                pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2);
+                pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2, wlo, whi);
             }
             cur = nxt;
             pp_spread_row<FUSED>(rown, sigma2, apc, upc);
@@ -695,11 +745,12 @@ hipError_t launch_assemble_small(hipStream_t s, const DevProblem &p, const int32
 
 hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
                                   const double *, const double *, double *, double, double, double *, double *, double *,
-                                  double *, int *, double *, double *);
+                                  double *, int *, double *, double *, const PPGather *);
 
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
-                                  double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb) {
+                                  double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb,
+                                  double *cc_partial) {
     if (n_list <= 0) return hipSuccess;
     const int schur = sb.active ? 1 : 0;
     hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
@@ -707,13 +758,15 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     double s2 = sigma2;
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
         hipError_t he = launch_schur_eliminate(s, p, blk_list, n_list, max_m, ip_list, n_ip_list, rowsA, rowsW, T, sigma2,
-                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr, sb.xq);
+                                               sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr, sb.xq,
+                                               pp.range_sub && pp.pt_ip_begin ? &pp : nullptr);
         if (he != hipSuccess) return he;
         if (sb.materialise) q.blk_w = sb.Pp;
         s2 = 1.0;
     }
-    static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::max(1, atoi(getenv("JAICOV_CC_PARTS"))) : 8;
-    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, s, p, blk_list, rowsA, T, s2, N, n, schur);
+    static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::min(16, std::max(1, atoi(getenv("JAICOV_CC_PARTS")))) : 8;
+    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, s, p, blk_list, rowsA, T, s2, cc_partial, schur);
+    hipLaunchKernelGGL(blk_cc_reduce_kernel, dim3(CC_ENT, p.n_cameras), dim3(256), 0, s, p, blk_list, n_list, cc_parts, cc_partial, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
     static const bool pc_atomic = getenv("JAICOV_PC_ATOMIC") != nullptr;
     if (pp.pt_ip_begin && !pc_atomic) {
@@ -723,11 +776,15 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
                            ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
     if (pp.pt_ip_begin) {
-        if (schur && !sb.materialise)   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
-            hipLaunchKernelGGL(blk_pp_gather_kernel<true>, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, p, pp, rowsA, sb.U, sigma2, N);
-        else
-            hipLaunchKernelGGL(blk_pp_gather_kernel<false>, dim3(p.n_points, pp.n_chunks), dim3(PP_NT), 0, s, q, pp, rowsA,
-                               (const double *)nullptr, s2, N);
+        const dim3 gg(p.n_points, pp.n_chunks), gb(PP_NT);
+        const bool det = pp.range_sub != nullptr;
+        if (schur && !sb.materialise) {   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
+            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, 0, s, p, pp, rowsA, sb.U, sigma2, N);
+            else hipLaunchKernelGGL((blk_pp_gather_kernel<true, false>), gg, gb, 0, s, p, pp, rowsA, sb.U, sigma2, N);
+        } else {
+            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<false, true>), gg, gb, 0, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+            else hipLaunchKernelGGL((blk_pp_gather_kernel<false, false>), gg, gb, 0, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+        }
     } else {
         if (schur && !sb.materialise) return hipErrorInvalidValue;   // the per-pair atomic kernel reads a materialised P'
         const int mp = max_m / 2;

@@ -24,7 +24,7 @@ hipError_t launch_assemble_small(hipStream_t, const DevProblem &, const int32_t 
                                  const double *, double, double *, double *);
 hipError_t launch_assemble_blocks(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
                                   const double *, const double *, double *, double, double *, double *, const PPGather &,
-                                  const SchurBufs &);
+                                  const SchurBufs &, double *);
 hipError_t launch_schur_backsub(hipStream_t, const DevProblem &, const int32_t *, int, const double *, const double *,
                                 const double *, double *);
 hipError_t launch_shared_groups(hipStream_t, const DevProblem &, const double *, double, double *, double *,
@@ -200,12 +200,14 @@ struct jaicov_engine {
     double *d_N = nullptr, *d_n = nullptr;          // one allocation: N (Upad x Upad) followed by n (Upad)
     double *d_packed = nullptr;                     // reduce buffer: packed N (U(U+1)/2) + n (U)
     double *d_V = nullptr, *d_B = nullptr, *d_dx = nullptr;
+    double *d_cc_partial = nullptr;                 // [blocks of this engine][16 parts][KC_MAX (KC_MAX + 1)] partial camera blocks (assemble.hip)
     double *d_omega = nullptr, *d_G = nullptr, *d_H = nullptr, *d_F = nullptr, *d_E = nullptr;
     int32_t *d_idx = nullptr;
     DenseSolver solver;
     bool solver_has_inverse = false;
     enum { ST_NEW, ST_PARAMS, ST_ACCUMULATED, ST_BUILT, ST_SOLVED } state = ST_NEW;
     bool have_Q = false, rows_valid = false, reduced = false;
+    bool deterministic = false;  // engine option / JAICOV_DETERMINISTIC: fixed summation order in the assembly of the image groups
     std::atomic<int> cancel{0};  // BundleAdjustment.interrupt() (BA:1455): polled by estimate() where the reference polls (BA:240, 320)
     bool sim_built = false;      // the system at hand was built with simulation != 0: the right-hand side is zero for ALL unknowns (BA:830-831)
     double lambda_used = 0.0;
@@ -304,6 +306,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     std::vector<int32_t> pv_image, pv_point, perm_local;
     std::vector<double> pv_x, pv_y, pv_vx, pv_vy, pv_rho;
     HIPE(e, hipSetDevice(e->device));
+    e->deterministic = e->opts.deterministic != 0;
+    if (const char *dv = getenv("JAICOV_DETERMINISTIC")) e->deterministic = atoi(dv) != 0;
     hipDeviceProp_t prop;
     HIPE(e, hipGetDeviceProperties(&prop, e->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -556,6 +560,33 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = upload(e, recs.data(), recs.size(), &e->pp.recs))) return rc;
             if ((rc = upload(e, ipcol.data(), ipcol.size(), &e->pp.ipcol))) return rc;
             if ((rc = upload(e, range.data(), range.size(), &e->pp.range))) return rc;
+            if (e->deterministic) {
+                // the same per SUB-chunk of PP_CW / 4 columns: one wave of the gather owns one (assemble.hip, DET)
+                const int CW4 = PP_CW / 4, n_sub = 4 * n_chunks;
+                std::vector<int32_t> sub_lo((size_t)blk_list.size() * n_sub), sub_hi((size_t)blk_list.size() * n_sub);
+                for (size_t t = 0; t < blk_list.size(); t++) {
+                    const int g = blk_list[t], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
+                    for (int c = 0; c < n_sub; c++) {
+                        const int c0 = cmin + c * CW4, c1 = c0 + CW4;
+                        int lo = mp, hi = 0;
+                        for (int j = 0; j < mp; j++)
+                            if (hi_col[ipb + j] >= c0 && lo_col[ipb + j] < c1) { lo = std::min(lo, j); hi = j + 1; }
+                        sub_lo[t * n_sub + c] = lo; sub_hi[t * n_sub + c] = std::max(hi, lo);
+                    }
+                }
+                std::vector<int32_t> range_sub((size_t)2 * list.size() * n_sub);
+                for (size_t o = 0; o < list.size(); o++) {
+                    const int ip = list[o], g = blk_of_ip[ip], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
+                    const int t = blk_pos[g];
+                    const int qend = (int)(std::upper_bound(lo_col.begin() + ipb, lo_col.begin() + ipb + mp, hi_col[ip]) - (lo_col.begin() + ipb));
+                    for (int c = 0; c < n_sub; c++) {
+                        const int lo = sub_lo[(size_t)t * n_sub + c], hi = std::min(sub_hi[(size_t)t * n_sub + c], qend);
+                        range_sub[2 * (o * n_sub + c)] = lo;
+                        range_sub[2 * (o * n_sub + c) + 1] = std::max(hi, lo);
+                    }
+                }
+                if ((rc = upload(e, range_sub.data(), range_sub.size(), &e->pp.range_sub))) return rc;
+            }
             e->pp.cmin = cmin;
             e->pp.n_chunks = n_chunks;
             e->pp.cmax = cmax;
@@ -640,6 +671,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_F, true))) return rc;
     if ((rc = dalloc(e, (size_t)64, &e->d_E, true))) return rc;
     if ((rc = dalloc(e, (size_t)1, &e->d_omega, true))) return rc;
+    if ((rc = dalloc(e, (size_t)std::max(1, e->n_blk_list) * 16 * KC_MAX * (KC_MAX + 1), &e->d_cc_partial))) return rc;
     HIPE(e, e->solver.init(e->stream, e->Upad, false, true));
     // ---- EO pre-elimination is possible when every image point sits in an image block, the EO columns are the
     //      trailing columns e0 + 6*image + k, and no directly observed parameter is an EO parameter ------------------
@@ -782,7 +814,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
         PPGather ppg = e->pp;
         ppg.plain = plain ? 1 : 0;
         HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
-                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, ppg, sb));
+                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, ppg, sb, e->d_cc_partial));
     }
     if (plain)   // the images outside the dense blocks come after the stores
         HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));

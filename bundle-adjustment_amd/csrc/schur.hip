@@ -24,8 +24,10 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
                                                        double *__restrict__ Ubuf, double *__restrict__ Linv_out,
                                                        double *__restrict__ G_out, int *info, double *__restrict__ xq) {
     __shared__ double red[42];        // E (36) + nE (6)
+    __shared__ double redw[4][42];    // per-wave partial sums: summed in wave order (LDS atomics would sum in arrival order)
     __shared__ double Linv[36];
     __shared__ double Gs[6 * SCHUR_GLD];
+    __shared__ double Gp[8][6 * SCHUR_GLD];   // per row-group partial sums of G, summed in group order
     const int tid = threadIdx.x;
     const int g = blk_list[blockIdx.x];
     const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb, m = 2 * mp;
@@ -33,7 +35,6 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
     const int img = p.ip_image[ipb], cam = p.image_camera[img];
     const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
     if (tid < 42) red[tid] = 0.0;
-    for (int i = tid; i < 6 * SCHUR_GLD; i += 256) Gs[i] = 0.0;
     __syncthreads();
     {
         double acc[42];
@@ -54,12 +55,14 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
         }
 #pragma unroll
         for (int i = 0; i < 42; i++) {
-            // wave reduction, then one LDS add per wave
+            // wave reduction, then one slot per wave
             double v = acc[i];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-            if ((tid & 63) == 0) atomicAdd(&red[i], v);
+            if ((tid & 63) == 0) redw[tid >> 6][i] = v;
         }
     }
+    __syncthreads();
+    if (tid < 42) red[tid] = (redw[0][tid] + redw[1][tid]) + (redw[2][tid] + redw[3][tid]);
     __syncthreads();
     if (tid == 0) {
         double E[6][6], Lm[6][6], Li[6][6];
@@ -129,11 +132,20 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
                 for (int k = 0; k < 6; k++) acc[k] += u[k] * a;
             }
 #pragma unroll
-            for (int k = 0; k < 6; k++) atomicAdd(&Gs[k * SCHUR_GLD + c], acc[k]);
+            for (int k = 0; k < 6; k++) Gp[rs][k * SCHUR_GLD + c] = acc[k];
+        } else if (c < SCHUR_GLD) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Gp[rs][k * SCHUR_GLD + c] = 0.0;
         }
     }
     __syncthreads();
-    for (int i = tid; i < 6 * SCHUR_GLD; i += 256) G_out[(long)img * 6 * SCHUR_GLD + i] = Gs[i];
+    for (int i = tid; i < 6 * SCHUR_GLD; i += 256) {
+        double v = 0.0;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; g8++) v += Gp[g8][i];
+        Gs[i] = v;
+        G_out[(long)img * 6 * SCHUR_GLD + i] = v;
+    }
 }
 
 // P' = sigma2 * Dinv - U U'   (row-major m x m; only the lower triangle including the 2 x 2 diagonal blocks is written:
@@ -209,12 +221,11 @@ __global__ __launch_bounds__(256) void blk_backsub_kernel(DevProblem p, const in
                                                           const double *__restrict__ Ubuf, const double *__restrict__ Linv,
                                                           const double *__restrict__ vbuf, double *__restrict__ xE) {
     __shared__ double t[6];
+    __shared__ double tw[4][6];       // per-wave partial sums, added in wave order (an LDS atomic would add in arrival order)
     const int tid = threadIdx.x;
     const int g = blk_list[blockIdx.x];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
     const int img = p.ip_image[ipb];
-    if (tid < 6) t[tid] = 0.0;
-    __syncthreads();
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int row = tid; row < m; row += 256) {
         const double v = vbuf[(long)2 * ipb + row];
@@ -226,8 +237,10 @@ __global__ __launch_bounds__(256) void blk_backsub_kernel(DevProblem p, const in
     for (int k = 0; k < 6; k++) {
         double v = acc[k];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if ((tid & 63) == 0) atomicAdd(&t[k], v);
+        if ((tid & 63) == 0) tw[tid >> 6][k] = v;
     }
+    __syncthreads();
+    if (tid < 6) t[tid] = (tw[0][tid] + tw[1][tid]) + (tw[2][tid] + tw[3][tid]);
     __syncthreads();
     if (tid < 6) {
         const double *Li = Linv + (long)img * 36;
@@ -278,17 +291,65 @@ __global__ __launch_bounds__(256) void blk_diagcorr_kernel(DevProblem p, const i
     unsafeAtomicAdd(diagcorr + col, s);
 }
 
+// the same without atomics (engine option `deterministic`): one thread owns one column.  Point columns: thread (point, b) walks
+// the point's incidences in the order of the gather's CSR; camera columns: thread (camera, c) walks the camera's blocks in list
+// order.  grid covers 3 * n_points + n_cameras * SCHUR_GLD threads.
+__global__ __launch_bounds__(256) void blk_diagcorr_det_kernel(DevProblem p, PPGather pp, const int32_t *__restrict__ blk_list, int n_blk,
+                                                               const double *__restrict__ rowsA, const double *__restrict__ Ubuf,
+                                                               const double *__restrict__ G, double *__restrict__ diagcorr) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long S = p.n_ip;
+    if (gid < (long)3 * p.n_points) {
+        const int pt = (int)(gid / 3), b = (int)(gid - 3L * pt);
+        const int col = p.point_col[3 * pt + b];
+        if (col < 0) return;
+        double s = 0.0;
+        for (int o = pp.pt_ip_begin[pt]; o < pp.pt_ip_begin[pt + 1]; o++) {
+            const int ip = pp.recs[o].ipb + pp.recs[o].lp;
+            const double a0 = rowsA[(long)(2 * b) * S + ip], a1 = rowsA[(long)(2 * b + 1) * S + ip];
+            const double *u0 = Ubuf + ((long)2 * ip) * 8, *u1 = u0 + 8;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const double y = u0[k] * a0 + u1[k] * a1;
+                s += y * y;
+            }
+        }
+        if (pp.pt_ip_begin[pt + 1] > pp.pt_ip_begin[pt]) diagcorr[col] += s;
+        return;
+    }
+    const long h = gid - (long)3 * p.n_points;
+    const int cam = (int)(h / SCHUR_GLD), c = (int)(h - (long)cam * SCHUR_GLD);
+    if (cam >= p.n_cameras) return;
+    const int jb = p.cam_dist_begin[cam], ncr = 3 + p.cam_dist_begin[cam + 1] - jb;
+    if (c >= ncr) return;
+    const int col = c < 3 ? p.io_col[3 * cam + c] : p.dist_col[jb + c - 3];
+    if (col < 0) return;
+    double s = 0.0;
+    for (int bi = 0; bi < n_blk; bi++) {
+        const int img = p.ip_image[p.blk_ip_begin[blk_list[bi]]];
+        if (p.image_camera[img] != cam) continue;
+        const double *Gi = G + (long)img * 6 * SCHUR_GLD;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += Gi[k * SCHUR_GLD + c] * Gi[k * SCHUR_GLD + c];
+    }
+    diagcorr[col] += s;
+}
+
 hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double lambda, double *Ubuf, double *Linv, double *G,
-                                  double *Pp, int *info, double *diagcorr, double *xq) {
+                                  double *Pp, int *info, double *diagcorr, double *xq, const PPGather *det_pp) {
     if (n_list <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_elim_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T, sigma2, lambda, Ubuf,
                        Linv, G, info, xq);
     if (Pp)   // only when P' is wanted in memory (JAICOV_PP_MATERIALISE / the atomic point x point kernel); the gather forms it on the fly
         hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 63) / 64, n_list), dim3(64, 4), 0, s, p, blk_list,
                            Ubuf, sigma2, Pp);
-    if (lambda > 0.0 && diagcorr) {
+    if (lambda > 0.0 && diagcorr && det_pp) {
+        const long nt = (long)3 * p.n_points + (long)p.n_cameras * SCHUR_GLD;
+        hipLaunchKernelGGL(blk_diagcorr_det_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, p, *det_pp, blk_list, n_list,
+                           rowsA, Ubuf, G, diagcorr);
+    } else if (lambda > 0.0 && diagcorr) {
         const long nt = (long)3 * n_ip_list + (long)n_list * SCHUR_GLD;
         hipLaunchKernelGGL(blk_diagcorr_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, p, ip_list, n_ip_list,
                            blk_list, n_list, rowsA, Ubuf, G, diagcorr);

@@ -157,7 +157,13 @@ typedef struct jaicov_engine_options {
                                       right-hand side scaled twice by the preconditioner, V_c^2 n_c (BA:261-267 solve only the
                                       leading numRows, BA:273 scales all of dx; BA:430, 450-461 then use these entries for Omega
                                       and the update) -- instead of the back-substituted step.  Default 0.      */
-    int32_t  reserved[7];
+    int32_t  deterministic;        /* != 0: the assembly of the jointly dispersed image groups sums in a fixed order (image order), so two
+                                      runs give the same bits in N and n.  The default lets the four waves of a workgroup of the
+                                      point x point gather add their images' terms in arrival order (LDS fp64 atomics): ~1e-16 relative
+                                      differences in N from run to run, which cond(N) ~ 1e9 turns into ~1e-9 in Qxx on the smallest
+                                      test scenes.  Costs 1.4 ms per pass at config 4 (assembly 3.5 -> 5.0 ms: every wave of the gather then
+                                      walks all images of its point).  JAICOV_DETERMINISTIC=0/1 overrides.                              */
+    int32_t  reserved[6];
 } jaicov_engine_options;
 
 typedef struct jaicov_engine jaicov_engine;
