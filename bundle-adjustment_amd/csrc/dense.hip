@@ -193,6 +193,13 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
 
+    // Which factorisation: the dataflow kernel pays one chain link (diagonal block -> panel tile -> next diagonal tile,
+    // 95-125 us) per block column whatever the order, the stream-scheduled one 60-90 us of launches and small kernels; the
+    // dataflow form wins once the trailing work hides its chain.  Measured on MI355X (scripts/flow_trace.py, ms per
+    // factorisation dataflow / streams): order 3712 3.10 / 2.51, 5120 4.35 / 3.76, 6144 5.30 / 4.76, 8192 7.25 / 7.92,
+    // 10240 9.5 / 12.6, 15104 22.5 / 26.3  ->  from 56 block columns on.
+    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 56;
+    const bool flow_wanted = !getenv("JAICOV_POTRF_LEGACY") && nfact / 128 >= flow_from;
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -200,8 +207,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask is CU i/8 of XCD i%8): the trailing
         // updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.  (Reserving fewer CUs was
         // measured: one or two reserved CUs cost 5 ms per factorisation at config 4, eight cost the update 3 % of the chip.)
-        static const bool legacy = getenv("JAICOV_POTRF_LEGACY") != nullptr;
-        if ((nfact >= 2048 || !legacy) && !getenv("JAICOV_NO_CUMASK")) {
+        if ((nfact >= 2048 || flow_wanted) && !getenv("JAICOV_NO_CUMASK")) {
             uint32_t upd[8], dia[8];
             for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
             // reserved: CU 31 of every XCD (8 CUs, what the stream-scheduled factorisation was tuned with), or of XCD 7 only
@@ -236,7 +242,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         HIPCHK(hipMalloc(&W, sq));
         HIPCHK(hipMalloc(&Q, sq));
     }
-    if (!getenv("JAICOV_POTRF_LEGACY") && dstream) {
+    if (flow_wanted && dstream) {
         hipError_t fe = flow_init();
         if (fe != hipSuccess) { flow_release(); (void)hipGetLastError(); }   // the stream-scheduled factorisation remains
     }

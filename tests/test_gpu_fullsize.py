@@ -58,9 +58,10 @@ def _adjust(eng, fp, mode, passes=5):
     return first, eng.get_parameters()
 
 
-def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4):
-    """Three independent device paths -- EO-reduced factorisation (order 15 014), full-order factorisation (18 014),
-    densified MFMA assembly + full order -- give the same adjustment.  The normal matrix of this scene has a condition
+def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4, monkeypatch):
+    """Four independent device paths -- EO-reduced dataflow factorisation (order 15 014), full-order factorisation
+    (18 014), densified MFMA assembly, and the stream-scheduled factorisation (the one orders below 56 block columns
+    take) -- give the same adjustment.  The normal matrix of this scene has a condition
     number of order 1e9 after Jacobi scaling, so a single step agrees to cond * eps (1e-7 of the largest entry) while the
     converged estimates, which are what north_star's 1e-9 speaks about, agree to 1e-10: Newton's iteration corrects the
     solver's rounding, only the residual evaluation limits the fixed point."""
@@ -76,7 +77,8 @@ def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4):
     N, n = a.get_normal()                                # the EO-reduced system the step was computed from:
     Nf = packed_to_full(N[:e0 * (e0 + 1) // 2], e0)      # the leading block of the packed 'U' array
     r = Nf @ dx_red[:e0] - n[:e0]
-    assert np.abs(r).max() <= 1e-9 * (np.abs(Nf) @ np.abs(dx_red[:e0])).max()
+    bound = (np.abs(Nf) @ np.abs(dx_red[:e0])).max()
+    assert np.abs(r).max() <= 1e-9 * bound, ("residual of the reduced system", np.abs(r).max(), bound)
     del Nf, N
     dx1_red, v_red = _adjust(a, fp, engine.INVERT_NONE)
     dx1_full, v_full = _adjust(a, fp, engine.INVERT_FULL)    # prepare_inverse(FULL): the build assembles the full-order system
@@ -84,9 +86,14 @@ def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4):
     d = engine.Engine(fp, assembly_mode=1)               # third path: J'WJ as dense A'(PA) on the matrix cores
     dx1_dense, v_dense = _adjust(d, fp, engine.INVERT_NONE)
     d.close()
+    monkeypatch.setenv("JAICOV_POTRF_LEGACY", "1")       # read when the solver is created
+    g = engine.Engine(fp)
+    monkeypatch.delenv("JAICOV_POTRF_LEGACY")
+    dx1_streams, v_streams = _adjust(g, fp, engine.INVERT_NONE)
+    g.close()
     scale = np.abs(dx1_full).max()
-    for other in (dx1_red, dx1_dense):
-        assert np.abs(other - dx1_full).max() < 1e-6 * scale
+    for name, other in (("reduced", dx1_red), ("dense", dx1_dense), ("streams", dx1_streams)):
+        assert np.abs(other - dx1_full).max() < 1e-6 * scale, ("first step", name, np.abs(other - dx1_full).max(), scale)
     # slots: [3P points | 3 per camera | distortion | 6 per image]; coordinates and camera stations are judged against
     # the extent of the object (2 000 mm), every other parameter against its own magnitude (floor 1.0)
     P3, I6 = 3 * fp.n_points, 6 * fp.n_images
@@ -94,9 +101,9 @@ def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4):
     den[:P3] = 2000.0
     eo = den[-I6:].reshape(-1, 6)
     eo[:, :3] = 2000.0
-    for other in (v_red, v_dense):
+    for name, other in (("reduced", v_red), ("dense", v_dense), ("streams", v_streams)):
         rel = np.abs(other - v_full) / den
-        assert rel.max() < 1e-10, (rel[:P3].max(), rel[P3:-I6].max(), rel[-I6:].max(), np.abs(other - v_full).max())
+        assert rel.max() < 1e-10, ("adjusted", name, rel[:P3].max(), rel[P3:-I6].max(), rel[-I6:].max(), np.abs(other - v_full).max())
 
 
 def test_cfg4_cofactor_matrices(cfg4, converged):

@@ -55,6 +55,24 @@ def test_dense_spd_solve_and_inverse(n):
     np.testing.assert_allclose(packed_to_full(ap, n), np.linalg.inv(S), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [128, 300, 1000, 2100])
+def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
+    """The dataflow Cholesky (csrc/cholflow.hip) is the default from 56 block columns on; forced here on 1, 3, 8 and 17
+    block columns (ragged last block included), against LAPACK."""
+    monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
+    rng = np.random.default_rng(n + 1)
+    G = rng.normal(size=(n, n + 20))
+    S = G @ G.T / n + np.eye(n)
+    b = rng.normal(size=(3, n))
+    x, ap, _ = engine.dense_spd_solve_packed(full_to_packed(S), b, invert=True)
+    np.testing.assert_allclose(x, np.linalg.solve(S, b.T).T, rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(packed_to_full(ap, n), np.linalg.inv(S), rtol=1e-9, atol=1e-12)
+    with pytest.raises(engine.EngineError) as ei:
+        S[n // 2, n // 2] = -1.0
+        engine.dense_spd_solve_packed(full_to_packed(S), b)
+    assert ei.value.code == 1
+
+
 def test_dense_not_spd_reports_singular():
     S = -np.eye(130)
     with pytest.raises(engine.EngineError) as ei:
@@ -486,9 +504,13 @@ def test_fp32_accumulate_contraction_is_measurably_worse(oracle_mod):
     np.testing.assert_allclose(dxs[1], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
 
 
-def test_config3_step_against_oracle(oracle_mod):
+@pytest.mark.parametrize("factorisation", ["default", "dataflow"])
+def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     """BASELINE config 3 (100 images x 1 000 points, full interior set, 2x2 correlated image points, U = 3 614): one pass
-    against the oracle's packed Bunch-Kaufman solve, normal equations included."""
+    against the oracle's packed Bunch-Kaufman solve, normal equations included.  At this order (24 block columns after
+    the EO reduction) the default is the stream-scheduled factorisation; the second case forces the dataflow kernel."""
+    if factorisation == "dataflow":
+        monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
     fp = scene.config("cfg3")
     o = oracle_mod.Oracle(fp)
     s2 = fp.sigma2apriori
