@@ -49,7 +49,7 @@ namespace jaicov {
     } while (0)
 
 // control words
-enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CTRL_WORDS = 16 };
+enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CHAIN_AT = 3, FLOW_STALE = 4, FLOW_STALE_CONFIRMED = 5, FLOW_CTRL_WORDS = 16 };   // CHAIN_AT: column << 4 | stage of the chain workgroup
 constexpr int FLOW_FIN = 1 << 20;        // task.w = k1 | FLOW_FIN: finish the tile after the updates
 constexpr int FLOW_LDS = 144;            // LDS row stride of both operands (gemm_f64.h: == 16 mod 32 doubles)
 constexpr int FLOW_STAGE = GEMM_BK * 2 * FLOW_LDS;
@@ -64,10 +64,11 @@ struct FlowArgs {
     int fs;                  // row stride of done / applied
     int *ctrl;               // FLOW_CTRL_WORDS control words
     int *done;               // [row blocks][fs]  L[i][k] is final (done[k][k]: set by the diagonal kernel, inv(L_kk) too)
-    int *applied;            // [row blocks][fs]  block columns [0, applied) have been subtracted from the stored tile (partial visits)
+    int *applied;            // [row blocks][fs]  applied - 1 block columns have been subtracted from the stored tile (partial visits; 0 = not stored yet)
     int *diag_ready;         // [nb] the updated diagonal tile is in memory
+    int *factored;           // [nb] chain form: L_cc is in memory (the inverse follows, done[c][c])
     int *info;               // first failing pivot (dense.h)
-    int *alive;              // host-visible word: the diagonal kernel stores `seq` there when it starts (potrf_flow's handshake)
+    int *alive;              // host-visible words: workgroup b of the diagonal / chain kernel stores `seq` into alive[b] when it starts (potrf_flow's handshake)
     int seq;
     // optional: the matrix is not in L yet but is M = V N V + Bh' Bh (identity on the d border rows and on the padding) of a
     // source square N (NES.applyPrecondition, NES:82-91, fused into the first load of every tile; engine.hip scale_copy_kernel)
@@ -81,17 +82,27 @@ struct FlowArgs {
     double *scratch;         // [grid][128 x 128] per workgroup: operand of the multiplication by inv(L_jj)'
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
     int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
-    int crit_prio;           // s_setprio level of the tasks on the critical chain (tiles (j,j) and (j+1,j)); 0 = none
+    int crit_prio;           // s_setprio level of the tasks on the critical chain; 0 = none
+    int crit_span;           // ... which are the tiles (i, j) with i <= j + crit_span
+    int *wgstate;            // [grid] where each workgroup is: ticket << 12 | k << 4 | stage (flow_report_stall reads it after a stall)
+    long long *ctrace;       // optional [nb][8], chain kernel: potrf start, factor done, operands there, solve done, update done (wall clock)
     long long *trace;        // optional [n_tasks][8]: start, C loaded, updates done, end (wall clock), ticks spent waiting, cycles, block, HW_ID | XCC_ID << 32
 };
 
 __device__ __forceinline__ int flow_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the same word read by a read-modify-write at agent scope: performed where all XCDs agree (never served from an L2 line)
+__device__ __forceinline__ int flow_ld_rmw(const int *p) { return __hip_atomic_fetch_or(const_cast<int *>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void flow_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void store_wt(double *p, double v) {   // write-through (sc1) store of one double
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void store_wt2(double *p, d2_t v) {   // the same for 16 bytes (no builtin for a 16-byte atomic store)
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#define FLOW_OPAQUE_TID(name) int name = tid; asm volatile("" : "+v"(name))
 
 // One lane: spin until *flag >= want.  Returns false when the factorisation is abandoned (abort word set / timeout).
 __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, long long timeout, long long *waited) {
@@ -105,6 +116,11 @@ __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, 
         else {
             __builtin_amdgcn_s_sleep(40);
             if ((spins & 31) == 0) {
+                if (flow_ld_rmw(flag) >= want) {      // set; did the plain poll only just miss it, or does it still not see it?
+                    atomicAdd(ctrl + FLOW_STALE, 1);
+                    if (flow_ld(flag) < want) atomicAdd(ctrl + FLOW_STALE_CONFIRMED, 1);
+                    break;
+                }
                 if (flow_ld(ctrl + FLOW_ABORT) != 0) { ok = false; break; }
                 if (wall_clock64() - t0 > timeout) { flow_st(ctrl + FLOW_ABORT, 2); ok = false; break; }
             }
@@ -134,7 +150,6 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
     // through: hoisted out of the persistent loop those values (dozens of them) stay live across the MFMA loop, the kernel
     // spills, and a kernel with a scratch segment is admitted with fewer waves per shader engine (measured: 458 of the 496
     // workgroups resident).
-#define FLOW_OPAQUE_TID(name) int name = tid; asm volatile("" : "+v"(name))
 
     d4_t acc[4][4];
     // acc += asign * A B' over nk k-steps of 16: A(x, k) = Ap[x * lda + k], B(y, k) = Bp[y * ldb + k], x, y < 128.  The sign
@@ -234,6 +249,8 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
         if (t >= g.n_tasks) break;
         const int4 tk = g.tasks[t];
         const int ti = tk.x, tj = tk.y, k0 = tk.z, k1 = tk.w & (FLOW_FIN - 1);
+#define FLOW_STAGE_MARK(kk, st) do { if (tid == 0) flow_st(g.wgstate + blockIdx.x, (t << 12) | ((kk) << 4) | (st)); } while (0)
+        FLOW_STAGE_MARK(k0, 1);
         const bool fin = (tk.w & FLOW_FIN) != 0;
         long long waited = 0, t_start = 0, t_c = 0, t_upd = 0, c_c = 0, c_upd = 0, w_upd = 0;
         int n_runs = 0;
@@ -241,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
         bool ok = true;
         // the chain diag(j) -> L[j+1][j] -> tile (j+1,j+1) -> diag(j+1) bounds the whole factorisation whenever the trailing work is
         // short: its two tile tasks take the matrix pipe ahead of the workgroup they share their SIMDs with
-        const bool critical = fin && ti <= tj + 1 && g.crit_prio > 0;
+        const bool critical = ti <= tj + g.crit_span && g.crit_prio > 0;
         if (critical) __builtin_amdgcn_s_setprio(3);
         // ---- one or two phases, each: accumulators <- memory, runs of MFMA work, accumulators -> memory.  Phase 0: the tile
         //      and its updates.  Phase 1 (off-diagonal tile that is to be finished): zeros, then C inv(L_jj)' with C read back
@@ -251,10 +268,11 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
         for (int phase = 0;; phase++) {
             // -- what has to be there before the accumulators are loaded
             if ((phase == 0 && k0 > 0) || phase == 1) {
+                FLOW_STAGE_MARK(k, 2);
                 if (tid == 0) {
                     // phase 0: an earlier (partial) visit wrote the tile; phase 1: inv(L_jj) from the diagonal kernel
                     const int *f = phase == 0 ? g.applied + (long)ti * g.fs + tj : g.done + (long)tj * g.fs + tj;
-                    const bool r = flow_spin(f, phase == 0 ? k0 : 1, g.ctrl, g.timeout, &waited);
+                    const bool r = flow_spin(f, phase == 0 ? k0 + 1 : 1, g.ctrl, g.timeout, &waited);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     drain_stores();
                     s_msg[1] = r ? 1 : 0;
@@ -312,6 +330,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                 double asign;
                 if (phase == 0) {
                     if (k >= k1) break;
+                    FLOW_STAGE_MARK(k, 3);
                     if (tid < 64) {
                         FLOW_OPAQUE_TID(lane);
                         const int *fi = g.done + (long)ti * g.fs, *fj = g.done + (long)tj * g.fs;
@@ -327,6 +346,18 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                             else {
                                 __builtin_amdgcn_s_sleep(40);
                                 if ((spins & 31) == 0) {
+                                    const bool ready2 = idx < k1 && flow_ld_rmw(fi + idx) != 0 && flow_ld_rmw(fj + idx) != 0;
+                                    const unsigned long long m2 = __ballot(ready2);
+                                    cnt = m2 == ~0ull ? 64 : __builtin_ctzll(~m2);
+                                    if (cnt > 0) {
+                                        const bool again = idx < k1 && flow_ld(fi + idx) != 0 && flow_ld(fj + idx) != 0;
+                                        const unsigned long long m3 = __ballot(again);
+                                        if (lane == 0) {
+                                            atomicAdd(g.ctrl + FLOW_STALE, 1);
+                                            if ((m3 & 1ull) == 0) atomicAdd(g.ctrl + FLOW_STALE_CONFIRMED, 1);   // the plain poll still misses it
+                                        }
+                                        break;
+                                    }
                                     if (flow_ld(g.ctrl + FLOW_ABORT) != 0) break;
                                     if (wall_clock64() - t0 > g.timeout) { flow_st(g.ctrl + FLOW_ABORT, 2); break; }
                                 }
@@ -342,6 +373,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                     __syncthreads();
                     if (cnt == 0) { ok = false; break; }
                     ++n_runs;
+                    FLOW_STAGE_MARK(k, 4);
                     Ap = g.L + (long)(g.fake_a ? tj : ti) * 128 * g.ld + (long)k * 128;
                     Bp = g.L + (long)tj * 128 * g.ld + (long)k * 128;
                     lda = ldb = g.ld;
@@ -361,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             if (!ok) break;
             if (g.trace && phase == 0) { t_upd = wall_clock64(); c_upd = clock64(); w_upd = waited; }
             // -- where the accumulators go, and which flag tells whom
+            FLOW_STAGE_MARK(k, 5 + phase);
             const bool to_scratch = phase == 0 && fin && ti != tj;
             {
                 FLOW_OPAQUE_TID(tq);
@@ -402,11 +435,12 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             if (tid == 0) {
                 if (phase == 1) flow_st(g.done + (long)ti * g.fs + tj, 1);                 // L[i][j] is final
                 else if (fin) flow_st(g.diag_ready + tj, 1);                               // updated diagonal tile, for the diagonal kernel
-                else flow_st(g.applied + (long)ti * g.fs + tj, k1);                        // partial visit
+                else flow_st(g.applied + (long)ti * g.fs + tj, k1 + 1);                    // partial visit (chain form: the tile is the chain workgroup's from here)
             }
             break;
         }
         if (critical) __builtin_amdgcn_s_setprio(0);
+        FLOW_STAGE_MARK(k, ok ? 7 : 8);
         if (!ok) break;
         if (g.trace && tid == 0) {
             long long *tr = g.trace + 8 * (long)t;
@@ -449,22 +483,256 @@ __global__ __launch_bounds__(256) void potrf_diag_chain_kernel(FlowArgs g) {
     }
 }
 
+// L[c+1][c] = T L_cc^-T for the tile T at Tg, transposed: Y = L_cc^-1 T' by block forward substitution with the factor in S and
+// the inverses of its 16x16 diagonal blocks in Wd; block row q is finished (times inv(L_qq)), then subtracted from the block
+// rows below.  Y stays in the accumulators throughout: the C/D registers of a finished block row are the B operand of the
+// products that follow.  Index trick: the MFMA puts row l4 + 4r of a 16-row result into register r of lane group l4; feeding
+// the A operand (blocks of L_cc) with rows AND columns permuted by pi(4a + b) = 4b + a makes that register hold row 4 l4 + r
+// instead, so a lane owns four CONSECUTIVE columns of its row of T: 32-byte pieces in memory, whole lines per instruction,
+// for the load and for the store (8-byte pieces cost 8 us more per link of the chain).
+// wave w: rows 32w .. 32w+31 of T.  y[p][cc][r] = element (32w + 16cc + l15, 16p + 4 l4 + r).
+__device__ __forceinline__ void chain_tile_load(const double *Tg, long ld, d4_t (&y)[8][2], const int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const double *tp = Tg + (long)(32 * wave + l15) * ld + 4 * l4;
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            const d2_t lo = *reinterpret_cast<const d2_t *>(tp + (long)(16 * cc) * ld + 16 * p);
+            const d2_t hi = *reinterpret_cast<const d2_t *>(tp + (long)(16 * cc) * ld + 16 * p + 2);
+            y[p][cc][0] = lo.x; y[p][cc][1] = lo.y; y[p][cc][2] = hi.x; y[p][cc][3] = hi.y;
+        }
+}
+__device__ __forceinline__ void chain_tile_solve(d4_t (&y)[8][2], const double *S, const double *Wd, const int tid) {
+    const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int pi15 = 4 * (l15 & 3) + (l15 >> 2);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            d4_t z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const double av = Wd[q * 16 * WDP + pi15 * WDP + 4 * l4 + ks];
+                z = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y[q][cc][ks], z, 0, 0, 0);
+            }
+            y[q][cc] = z;
+        }
+#pragma unroll
+        for (int p = q + 1; p < 8; p++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const double av = -S[(16 * p + pi15) * DP + 16 * q + 4 * l4 + ks];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) y[p][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y[q][cc][ks], y[p][cc], 0, 0, 0);
+            }
+    }
+}
+__device__ __forceinline__ void chain_tile_store(double *Tg, long ld, const d4_t (&y)[8][2], const int tid) {   // write-through
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    double *tp = Tg + (long)(32 * wave + l15) * ld + 4 * l4;
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++) {
+            d2_t lo, hi;
+            lo.x = y[p][cc][0]; lo.y = y[p][cc][1]; hi.x = y[p][cc][2]; hi.y = y[p][cc][3];
+            store_wt2(tp + (long)(16 * cc) * ld + 16 * p, lo);
+            store_wt2(tp + (long)(16 * cc) * ld + 16 * p + 2, hi);
+        }
+}
+
+// One link of the chain after potrf(c): S holds L_cc, Wd the inverses of its 16x16 diagonal blocks; tile (c+1, c) and the
+// diagonal tile (c+1, c+1) are in memory.  Leaves L[c+1][c] in memory (write-through, drained) and the updated diagonal tile in
+// S.
+__device__ __forceinline__ void chain_solve_update(double *Tg, long ld, long long *tr, double *S, double *Wd, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    // the 36 lower 16x16 tiles of the diagonal tile, nine per wave: wave w takes the tile rows w (w + 1 tiles) and 7 - w (8 - w)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+#define CHAIN_TILE_R(i) ((i) <= wv ? wv : 7 - wv)
+#define CHAIN_TILE_Q(i) ((i) <= wv ? (i) : (i) - wv - 1)
+    const double *Cg = Tg + 128;
+    d4_t y[8][2], cacc[9];
+    chain_tile_load(Tg, ld, y, tid);
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cacc[i][r] = Cg[(long)(16 * CHAIN_TILE_R(i) + l4 + 4 * r) * ld + 16 * CHAIN_TILE_Q(i) + l15];
+    if (tr) {
+        drain_stores();
+        tr[5] = wall_clock64();
+    }
+    chain_tile_solve(y, S, Wd, tid);
+    if (tr) tr[6] = wall_clock64();
+    chain_tile_store(Tg, ld, y, tid);
+    if (tr) tr[3] = wall_clock64();
+    __syncthreads();          // every wave has read L_cc and Wd for the last time
+    // ... and into S, row-major, as both operands of the update of the diagonal tile
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) S[(32 * wave + 16 * cc + l15) * DP + 16 * p + 4 * l4 + r] = y[p][cc][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double *sa = S + (16 * CHAIN_TILE_R(i) + l15) * DP + l4, *sb = S + (16 * CHAIN_TILE_Q(i) + l15) * DP + l4;
+#pragma unroll
+        for (int k = 0; k < 32; k++) cacc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(-sa[4 * k], sb[4 * k], cacc[i], 0, 0, 0);
+    }
+    __syncthreads();          // every wave has read L[c+1][c] for the last time: the next diagonal block takes S over
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = l4 + 4 * r;
+            S[(16 * CHAIN_TILE_R(i) + row) * DP + 16 * CHAIN_TILE_Q(i) + l15] = (CHAIN_TILE_R(i) == CHAIN_TILE_Q(i) && l15 > row) ? 0.0 : cacc[i][r];
+        }
+    drain_stores();           // L[c+1][c] has left
+    __syncthreads();
+}
+#undef CHAIN_TILE_R
+#undef CHAIN_TILE_Q
+
+__device__ __forceinline__ void chain_factor(double *Acc, long ld, int *info, int c, double *S, double *Wd, const int tid, long long *tr) {
+    diag_factor(S, Wd, info, c, 0, tid);
+    if (tr) tr[7] = wall_clock64();
+    // L_cc to memory, write-through (no cache-wide release on the chain); the flag follows once every wave has drained
+#pragma unroll 8
+    for (int i = 0; i < 32; i++) {
+        const int idx2 = tid + 256 * i;
+        const int r = idx2 >> 6, cc = 2 * (idx2 & 63);
+        if (cc <= r) {
+            d2_t v;
+            v.x = S[r * DP + cc];
+            v.y = S[r * DP + cc + 1];
+            store_wt2(Acc + (long)r * ld + cc, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Chain form of the diagonal kernel: TWO workgroups, each on a reserved CU of its own.
+//
+//   workgroup 0   keeps the whole critical chain of the factorisation inside one CU: potrf(c) in LDS -> L[c+1][c] = T L_cc^-T
+//                 -> the diagonal tile (c+1, c+1) minus L[c+1][c] L[c+1][c]' -> potrf(c+1) ... without a trip through memory,
+//                 flags and other workgroups in between (that trip: store, flag, poll, acquire, load, three times per block
+//                 column, 95-122 us per column where this loop needs about 50).  The tile kernel delivers T = tile (c+1, c) with
+//                 all its updates and the diagonal tile (c+1, c+1) with the updates of the block columns < c (partial visits).
+//                 The solve runs transposed, Y = L_cc^-1 T', by block forward substitution on the 16x16 diagonal-block
+//                 inverses that the factorisation leaves in Wd -- the full inverse of L_cc is not needed here -- with Y in the
+//                 accumulators from the load to the store: the C/D layout of a finished block row of Y is the B operand of the
+//                 products that subtract it from the block rows below (C/D rows (l>>4)+4r == B rows 4ks+(l>>4)).
+//   workgroup 1   inverts the factors (the tile kernel multiplies the other tiles of a block column by inv(L_cc)', a plain MFMA
+//                 product) beside the chain instead of inside it.
+__global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
+    __shared__ double S[128 * DP];
+    __shared__ double Wd[8 * 16 * WDP];
+    __shared__ int s_ok;
+    const int tid = threadIdx.x;
+    if (tid == 0 && g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (blockIdx.x == 1) {
+        // ---- the inverses ----------------------------------------------------------------------------------------------
+        for (int c = 0; c < g.nb; c++) {
+            if (tid == 0) {
+                const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                drain_stores();
+                s_ok = r ? 1 : 0;
+            }
+            __syncthreads();
+            const bool ok = s_ok != 0;
+            __syncthreads();
+            if (!ok) return;
+            FLOW_OPAQUE_TID(tq);      // see potrf_diag.h: nothing derived from the thread index is to live across this loop
+            diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
+            diag_block_inverses(S, Wd, tq);
+            __syncthreads();
+            diag_inverse(S, Wd, g.invd + (long)c * 16384, 0, tq);
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                drain_stores();
+                flow_st(g.done + (long)c * g.fs + c, 1);
+                flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
+            }
+            __syncthreads();      // S is loaded again
+        }
+        return;
+    }
+    // ---- the chain -------------------------------------------------------------------------------------------------
+    if (tid == 0) {
+        const bool r = flow_spin(g.applied, 1, g.ctrl, g.timeout, nullptr);      // tile (0, 0): scaled, in L
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        drain_stores();
+        s_ok = r ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_ok == 0) return;
+    __syncthreads();
+    diag_load(g.L, g.ld, S, tid);
+    for (int c = 0; c < g.nb; c++) {
+        long long *tr = g.ctrace && tid == 0 ? g.ctrace + 8 * (long)c : nullptr;
+        if (tr) tr[0] = wall_clock64();
+        if (tid == 0) flow_st(g.ctrl + FLOW_CHAIN_AT, (c << 4) | 1);
+        {
+            FLOW_OPAQUE_TID(tq);
+            chain_factor(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, g.info, c, S, Wd, tq, tr);
+        }
+        if (tr) tr[1] = wall_clock64();
+        // L_cc is on its way (write-through): the inverse workgroup may have it as soon as every wave's stores have landed --
+        // before this workgroup starts to wait for anything else
+        drain_stores();
+        __syncthreads();
+        if (tid == 64) flow_st(g.factored + c, 1);
+        if (c + 1 >= g.nb) break;
+        if (tid == 0) {
+            flow_st(g.ctrl + FLOW_CHAIN_AT, (c << 4) | 2);
+            bool r = flow_spin(g.applied + (long)(c + 1) * g.fs + c, c + 1, g.ctrl, g.timeout, nullptr);
+            r = r && flow_spin(g.applied + (long)(c + 1) * g.fs + c + 1, c + 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            s_ok = r ? 1 : 0;
+        }
+        __syncthreads();
+        const bool ok = s_ok != 0;
+        if (!ok) return;
+        if (tr) tr[2] = wall_clock64();
+        if (tid == 0) flow_st(g.ctrl + FLOW_CHAIN_AT, (c << 4) | 3);
+        {
+            FLOW_OPAQUE_TID(tq);
+            chain_solve_update(g.L + (long)(c + 1) * 128 * g.ld + (long)c * 128, g.ld, tr, S, Wd, tq);
+        }
+        if (tid == 64) flow_st(g.done + (long)(c + 1) * g.fs + c, 1);
+        if (tr) tr[4] = wall_clock64();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Task list: left-looking.  w = 1: column-major; column j: the diagonal tile first, then the tiles below it (the tile right
 // below feeds the next diagonal tile: it is the one the chain waits for), the right-hand-side rows last.  w > 1: groups of w
 // columns; the tiles of the group's diagonal blocks first, then row by row the w tiles of a row, which stream the same A
 // strip L[i][0..j) at the same time (the second reader finds it in L2 / the Infinity Cache).  Either way a tile only depends
 // on tiles that come earlier in the list.
-static std::vector<int4> flow_schedule(int nb, int row_blocks, int w) {
+static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain) {
     std::vector<int4> tasks;
     tasks.reserve((size_t)nb * (row_blocks + 1) / 2 + row_blocks);
     if (w < 1) w = 1;
+    // chain form (potrf_chain_kernel): the diagonal tile (j, j) is visited for the block columns < j - 1 only and the tile below
+    // it, (j + 1, j), is not finished: the chain workgroup takes both from there
+    auto task = [&](int i, int j) {
+        if (chain && i == j) return make_int4(i, j, 0, std::max(j - 1, 0));
+        if (chain && i == j + 1 && i < nb) return make_int4(i, j, 0, j);
+        return make_int4(i, j, 0, j | FLOW_FIN);
+    };
     for (int j0 = 0; j0 < nb; j0 += w) {
         const int j1 = std::min(nb, j0 + w);
         for (int j = j0; j < j1; j++)
-            for (int i = j; i < j1; i++) tasks.push_back(make_int4(i, j, 0, j | FLOW_FIN));
+            for (int i = j; i < j1; i++) tasks.push_back(task(i, j));
         for (int i = j1; i < row_blocks; i++)
-            for (int j = j0; j < j1; j++) tasks.push_back(make_int4(i, j, 0, j | FLOW_FIN));
+            for (int j = j0; j < j1; j++) tasks.push_back(task(i, j));
     }
     return tasks;
 }
@@ -507,12 +775,15 @@ bool DenseSolver::flow_kernels_overlap() {
 hipError_t DenseSolver::flow_init() {
     const int nb = nfact / 128, row_blocks = n / 128;
     if (!dstream) return hipErrorNotSupported;
-    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1);
+    // chain form unless kernels cannot run side by side (one-kernel form, diagonal blocks inline) or it is switched off
+    flow_chain = flow_kernels_overlap() && !(getenv("JAICOV_FLOW_CHAIN") && atoi(getenv("JAICOV_FLOW_CHAIN")) == 0);
+    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1, flow_chain);
     flow_tasks = (int)tasks.size();
+    flow_task_host = tasks;
     HIPCHK(hipMalloc(&flow_task_list, tasks.size() * sizeof(int4)));
     HIPCHK(hipMemcpy(flow_task_list, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
     flow_fs = nb;
-    flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + nb;
+    flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + 2 * nb + 1024;   // ... + one state word per workgroup
     HIPCHK(hipMalloc(&flow_flags, flow_words * sizeof(int)));
     HIPCHK(hipMemset(flow_flags, 0, flow_words * sizeof(int)));
     int cus = 256;
@@ -522,10 +793,11 @@ hipError_t DenseSolver::flow_init() {
     flow_grid = 2 * cus;             // two workgroups per CU; the CU of the diagonal kernel takes none, the surplus stays queued (harmless)
     if (const char *e = getenv("JAICOV_FLOW_GRID")) flow_grid = atoi(e);
     if (flow_grid < 1) flow_grid = 1;
+    if (flow_grid > 1024) flow_grid = 1024;
     HIPCHK(hipMalloc(&flow_scratch, ((size_t)flow_grid * 16384 + 64) * sizeof(double)));
     HIPCHK(hipMemset(flow_scratch + (size_t)flow_grid * 16384, 0, 64 * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&flow_alive, sizeof(int), hipHostMallocMapped));
-    *flow_alive = 0;
+    HIPCHK(hipHostMalloc((void **)&flow_alive, 2 * sizeof(int), hipHostMallocMapped));
+    flow_alive[0] = flow_alive[1] = 0;
     HIPCHK(hipEventCreateWithFlags(&flow_e0, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e1, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e2, hipEventDisableTiming));
@@ -561,6 +833,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.done = flow_flags + FLOW_CTRL_WORDS;
     g.applied = g.done + (size_t)row_blocks * nb;
     g.diag_ready = g.applied + (size_t)row_blocks * nb;
+    g.factored = g.diag_ready + nb;
+    g.wgstate = g.factored + nb;
     g.info = d_info;
     g.scratch = flow_scratch;
     g.zeros = flow_scratch + (size_t)flow_grid * 16384;
@@ -568,8 +842,10 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.src = flow_src; g.src_ld = flow_src_ld; g.V = flow_V; g.Bh = flow_Bh; g.d = flow_d; g.U = flow_U; g.bstride = flow_bstride;
     flow_src = nullptr;      // one factorisation only
     g.trace = flow_trace;
+    g.ctrace = flow_trace ? flow_trace + 8 * (size_t)flow_tasks : nullptr;
     g.fake_a = getenv("JAICOV_FLOW_FAKE_A") ? atoi(getenv("JAICOV_FLOW_FAKE_A")) : 0;
     g.crit_prio = getenv("JAICOV_FLOW_PRIO") ? atoi(getenv("JAICOV_FLOW_PRIO")) : 1;
+    g.crit_span = getenv("JAICOV_FLOW_PRIO_SPAN") ? atoi(getenv("JAICOV_FLOW_PRIO_SPAN")) : (flow_chain ? 2 : 1);
     g.alive = flow_alive;
     g.seq = ++flow_seq;
     HIPCHK(hipMemsetAsync(flow_flags, 0, flow_words * sizeof(int), stream));
@@ -593,7 +869,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     HIPCHK(hipEventRecord(flow_e0, stream));
     HIPCHK(hipStreamWaitEvent(dstream, flow_e0, 0));
     if (all_ready) HIPCHK(hipStreamWaitEvent(dstream, all_ready, 0));
-    hipLaunchKernelGGL(potrf_diag_chain_kernel, dim3(1), dim3(256), 0, dstream, g);
+    if (flow_chain) hipLaunchKernelGGL(potrf_chain_kernel, dim3(2), dim3(256), 0, dstream, g);
+    else hipLaunchKernelGGL(potrf_diag_chain_kernel, dim3(1), dim3(256), 0, dstream, g);
     HIPCHK(hipGetLastError());
     // Residency.  The diagonal kernel needs a whole CU's LDS and runs on the stream whose CU mask holds one CU of every XCD.
     // The tile kernel runs on the ORDINARY stream with all CUs: on a stream masked to the other 248 CUs only 458 of 496
@@ -604,7 +881,7 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     {
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
-        while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq) {
+        while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq || (flow_chain && __atomic_load_n(flow_alive + 1, __ATOMIC_ACQUIRE) != g.seq)) {
             if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
                 return hipErrorLaunchTimeOut;
         }
@@ -621,11 +898,54 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     return hipGetLastError();
 }
 
+// Error path (fetch_info found the abort word set): where did the factorisation stop?
+void DenseSolver::flow_report_stall() {
+    if (!flow_flags) return;
+    const int nb = nfact / 128, row_blocks = n / 128;
+    std::vector<int> f(flow_words);
+    if (hipMemcpy(f.data(), flow_flags, flow_words * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return;
+    const int *done = f.data() + FLOW_CTRL_WORDS, *applied = done + (size_t)row_blocks * nb;
+    const int *diag_ready = applied + (size_t)row_blocks * nb, *factored = diag_ready + nb;
+    int c_inv = 0, c_fac = 0, c_sub = 0;
+    while (c_inv < nb && done[(size_t)c_inv * nb + c_inv]) ++c_inv;
+    while (c_fac < nb && factored[c_fac]) ++c_fac;
+    while (c_sub + 1 < nb && done[(size_t)(c_sub + 1) * nb + c_sub]) ++c_sub;
+    int first_open = -1, open_row = -1;
+    for (int j = 0; j < nb && first_open < 0; j++)
+        for (int i = j + 1; i < row_blocks; i++)
+            if (!done[(size_t)i * nb + j]) { first_open = j; open_row = i; break; }
+    fprintf(stderr,
+            "jaicov: dataflow factorisation abandoned (abort %d): ticket %d of %d, chain form %d, blocks %d; inverses published %d, "
+            "factors published %d, subdiagonal tiles published %d, first unfinished tile (%d, %d), chain workgroup at column %d stage %d",
+            f[FLOW_ABORT], f[FLOW_TICKET], flow_tasks, (int)flow_chain, nb, c_inv, c_fac, c_sub, open_row, first_open, f[FLOW_CHAIN_AT] >> 4, f[FLOW_CHAIN_AT] & 15);
+    if (flow_chain && c_fac < nb) {
+        const int c = c_fac > 0 ? c_fac - 1 : 0;      // the column the chain workgroup was (probably) working on
+        if (c + 1 < nb)
+            fprintf(stderr, "; column %d: tile below stored with %d updates, next diagonal tile with %d (wanted %d)", c,
+                    applied[(size_t)(c + 1) * nb + c] - 1, applied[(size_t)(c + 1) * nb + c + 1] - 1, c);
+    }
+    fprintf(stderr, "\n");
+    // the oldest tickets still in flight, and what their workgroups were doing (1 drawn, 2 waiting for an earlier visit / the
+    // inverse, 3 polling operand flags at block column k, 4 products, 5 / 6 storing after phase 0 / 1, 7 finished, 8 gave up)
+    const int *wg = factored + nb;
+    std::vector<std::pair<int, int>> open;
+    for (int b = 0; b < std::min(flow_grid, 1024); b++)
+        if (wg[b] != 0 && (wg[b] & 15) != 7) open.push_back({wg[b] >> 12, b});
+    std::sort(open.begin(), open.end());
+    for (size_t q = 0; q < open.size() && q < 6; q++) {
+        const int w = wg[open[q].second], t = w >> 12;
+        const int4 tk = flow_task_host.empty() ? make_int4(-1, -1, 0, 0) : flow_task_host[t];
+        fprintf(stderr, "jaicov:   workgroup %d: ticket %d = tile (%d, %d) to block column %d%s, stage %d at block column %d\n", open[q].second, t, tk.x,
+                tk.y, tk.w & (FLOW_FIN - 1), (tk.w & FLOW_FIN) ? " + finish" : "", w & 15, (w >> 4) & 255);
+    }
+}
+
 // debug: per-task timeline of the next factorisations (scripts/flow_trace.py)
 hipError_t DenseSolver::flow_enable_trace(bool on) {
     if (on && !flow_trace) {
-        HIPCHK(hipMalloc(&flow_trace, (size_t)flow_tasks * 8 * sizeof(long long)));
-        HIPCHK(hipMemset(flow_trace, 0, (size_t)flow_tasks * 8 * sizeof(long long)));
+        const size_t words = ((size_t)flow_tasks + nfact / 128) * 8;      // per task, then per block column (chain kernel)
+        HIPCHK(hipMalloc(&flow_trace, words * sizeof(long long)));
+        HIPCHK(hipMemset(flow_trace, 0, words * sizeof(long long)));
     } else if (!on && flow_trace) {
         hipFree(flow_trace);
         flow_trace = nullptr;

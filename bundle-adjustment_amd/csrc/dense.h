@@ -51,7 +51,9 @@ struct DenseSolver {
     double flops_order = 0;              // real (unpadded) order of the matrix, for the algorithmic flop count n^3/3; 0 = nfact
 
     // dataflow factorisation (cholflow.hip): the whole potrf as two concurrent launches, dependencies as flags in memory
-    bool flow_ready = false, flow_timed = false;
+    bool flow_ready = false, flow_timed = false, flow_chain = false;
+    long long flow_stale_events = 0, flow_stale_confirmed = 0;   // flags that only the read-modify-write poll saw (fetch_info)
+    std::vector<int4> flow_task_host;    // the task list (flow_report_stall)
     int reserved_cus = 8;                // CUs kept free of the update stream for the diagonal-block kernel
     int4 *flow_task_list = nullptr;
     int flow_tasks = 0, flow_fs = 0, flow_grid = 0;
@@ -76,6 +78,7 @@ struct DenseSolver {
     hipError_t potrf_flow(hipEvent_t all_ready);
     hipError_t potrf_streams(hipEvent_t first_ready, hipEvent_t all_ready);   // the stream / event scheduled factorisation
     hipError_t flow_enable_trace(bool on);
+    void flow_report_stall();            // one line on stderr: how far the abandoned factorisation got
 
     hipError_t init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows = false);
     double *rhs_row(int q) const { return L + (long)(nfact + q) * ld; }   // row q of the right-hand sides / of Z = Y L^-T

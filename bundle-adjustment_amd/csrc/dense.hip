@@ -193,12 +193,13 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
 
-    // Which factorisation: the dataflow kernel pays one chain link (diagonal block -> panel tile -> next diagonal tile,
-    // 95-125 us) per block column whatever the order, the stream-scheduled one 60-90 us of launches and small kernels; the
-    // dataflow form wins once the trailing work hides its chain.  Measured on MI355X (scripts/flow_trace.py, ms per
-    // factorisation dataflow / streams): order 3712 3.10 / 2.51, 5120 4.35 / 3.76, 6144 5.30 / 4.76, 8192 7.25 / 7.92,
-    // 10240 9.5 / 12.6, 15104 22.5 / 26.3  ->  from 56 block columns on.
-    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 56;
+    // Which factorisation: both are bound by a chain of one link per block column while the order is small (dataflow: the
+    // chain workgroup's potrf -> solve -> update, ~80-95 us; streams: diagonal kernel + two dependent launches, ~80 us), the
+    // dataflow form then pays its start-up (two launches, a host handshake, ~0.15 ms).  Measured on MI355X
+    // (scripts/flow_trace.py, ms per factorisation dataflow / streams): order 1024 0.76 / 0.62, 2048 1.32 / 1.28,
+    // 3072 1.94 / 2.00, 3712 2.37 / 2.50, 5120 3.33 / 3.75, 6144 4.07 / 4.78, 8192 5.95 / 7.92, 15104 22.3 / 26.3
+    // -> from 24 block columns on.
+    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 24;
     const bool flow_wanted = !getenv("JAICOV_POTRF_LEGACY") && nfact / 128 >= flow_from;
     {
         int least = 0, greatest = 0;
@@ -606,10 +607,17 @@ void DenseSolver::prof_collect() {
 int DenseSolver::fetch_info() {
     int h = -1;
     if (hipMemcpyAsync(&h, d_info, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
-    int ab = 0;
-    if (flow_ready && hipMemcpyAsync(&ab, flow_flags + 1, sizeof(int), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
+    int cw[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // cholflow.hip's control words: [1] abort, [4] / [5] flags that the plain poll missed
+    if (flow_ready && hipMemcpyAsync(cw, flow_flags, sizeof(cw), hipMemcpyDeviceToHost, stream) != hipSuccess) return -1;
     if (hipStreamSynchronize(stream) != hipSuccess) return -1;
-    if (ab != 0) return -9;   // a wait of the dataflow factorisation ran into its time limit
+    const int ab = cw[1];
+    flow_stale_events += cw[4];
+    flow_stale_confirmed += cw[5];
+    if (cw[4] && getenv("JAICOV_VERBOSE")) fprintf(stderr, "jaicov: dataflow factorisation: %d flag(s) found by the read-modify-write poll, %d of them still invisible to the plain poll\n", cw[4], cw[5]);
+    if (ab != 0) {            // a wait of the dataflow factorisation ran into its time limit
+        flow_report_stall();
+        return -9;
+    }
     return h;
 }
 

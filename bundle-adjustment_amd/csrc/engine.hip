@@ -1592,7 +1592,7 @@ extern "C" int jaicov_debug_potrf_bench(int n, int reps, double *ms_out, long lo
             if (info != 0 && !getenv("JAICOV_FLOW_FAKE_A")) { status = JAICOV_ERR_SINGULAR; break; }
         }
         if (status == JAICOV_OK && trace_out && ds.flow_trace) {
-            const long long cnt = std::min<long long>(trace_cap, (long long)ds.flow_tasks * 8);
+            const long long cnt = std::min<long long>(trace_cap, ((long long)ds.flow_tasks + n / 128) * 8);   // per task, then per block column (chain kernel)
             hipMemcpy(trace_out, ds.flow_trace, (size_t)cnt * sizeof(long long), hipMemcpyDeviceToHost);
         }
         if (tasks_out) *tasks_out = ds.flow_ready ? ds.flow_tasks : 0;

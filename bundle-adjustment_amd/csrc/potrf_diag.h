@@ -87,11 +87,11 @@ __device__ __forceinline__ void diag_update_tile(double *S, int R, int Q, int c0
     for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + 16 * Q + l15] = acc[r];
 }
 
-// inv_out must be zero above the diagonal on entry (the buffer is zero-filled once at allocation).
-// S: 128 x DP doubles, Wd: 8 x 16 x WDP doubles of LDS owned by the calling workgroup (256 threads).
-__device__ __forceinline__ void potrf_diag_body(double *A, long ld, double *inv_out, int *info, int blk, int dbg, double *S, double *Wd) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
+// The four parts of potrf_diag_body, callable one by one (cholflow.hip's chain workgroups split them between two CUs).  tid =
+// threadIdx.x; a caller that runs them in a loop passes a copy the compiler cannot see through, so that the hundreds of
+// addresses derived from it are not hoisted out of that loop and kept alive in registers across it.
+// diag_load: block -> LDS (lower part, zeros above the diagonal).
+__device__ __forceinline__ void diag_load(const double *A, long ld, double *S, const int tid) {
     // block -> LDS: 16 independent 16-byte loads in flight per thread (a rolled load->store loop serialises on the
     // memory latency: 64 round trips, ~45 us)
 #pragma unroll
@@ -111,6 +111,12 @@ __device__ __forceinline__ void potrf_diag_body(double *A, long ld, double *inv_
         }
     }
     __syncthreads();
+}
+
+// diag_factor: S (lower part) <- L in place, Wd <- inverses of the eight 16x16 diagonal blocks of L.
+__device__ __forceinline__ void diag_factor(double *S, double *Wd, int *info, int blk, int dbg, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     if (wave == 0 && !(dbg & 1)) chol16_inv(S, Wd, 0, lane, info, blk);
     __syncthreads();
     for (int p = 0; p < 8; p++) {
@@ -146,7 +152,10 @@ __device__ __forceinline__ void potrf_diag_body(double *A, long ld, double *inv_
         }
         __syncthreads();
     }
-    // factor back to global (lower part; the strict upper part of a diagonal block is never read by anyone)
+}
+
+// diag_store_factor: factor back to global (lower part; the strict upper part of a diagonal block is never read by anyone)
+__device__ __forceinline__ void diag_store_factor(const double *S, double *A, long ld, const int tid) {
 #pragma unroll 8
     for (int i = 0; i < 32; i++) {
         const int idx2 = tid + 256 * i;
@@ -158,6 +167,13 @@ __device__ __forceinline__ void potrf_diag_body(double *A, long ld, double *inv_
             *reinterpret_cast<d2_t *>(A + (long)r * ld + c) = v;
         }
     }
+}
+
+// diag_inverse: inv_out <- L^-1 from the factor in S and the diagonal-block inverses in Wd (the strict upper part of S is
+// used as parking space).  inv_out must be zero above the diagonal on entry.
+__device__ __forceinline__ void diag_inverse(double *S, const double *Wd, double *inv_out, int dbg, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
     // ---- inverse, one block diagonal after the other ---------------------------------------------------------
     for (int t = 1; t < 8; t++) {
         if (dbg & 4) break;
@@ -200,6 +216,38 @@ __device__ __forceinline__ void potrf_diag_body(double *A, long ld, double *inv_
                               : (((r >> 4) == ((c + 1) >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + ((c + 1) & 15)]
                                                               : S[(c + 1) * DP + r]);
             *reinterpret_cast<d2_t *>(inv_out + r * 128 + c) = v;
+        }
+    }
+}
+
+// inv_out must be zero above the diagonal on entry (the buffer is zero-filled once at allocation).
+// S: 128 x DP doubles, Wd: 8 x 16 x WDP doubles of LDS owned by the calling workgroup (256 threads).
+__device__ __forceinline__ void potrf_diag_body(double *A, long ld, double *inv_out, int *info, int blk, int dbg, double *S, double *Wd) {
+    const int tid = threadIdx.x;
+    diag_load(A, ld, S, tid);
+    diag_factor(S, Wd, info, blk, dbg, tid);
+    diag_store_factor(S, A, ld, tid);
+    diag_inverse(S, Wd, inv_out, dbg, tid);
+}
+
+// Inverses of the eight 16x16 diagonal blocks of a factor that is already in S (a workgroup that did not factor it itself):
+// wave w takes blocks w and w + 4; lane c < 16 holds column c of the inverse (forward substitution as in chol16_inv).
+__device__ __forceinline__ void diag_block_inverses(const double *S, double *Wd, const int tid) {
+    const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15;
+    for (int b = wave; b < 8; b += 4) {
+        const int c0 = 16 * b;
+        double x[16], sres[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) sres[i] = (l15 == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            x[k] = sres[k] / S[(c0 + k) * DP + c0 + k];
+#pragma unroll
+            for (int i = k + 1; i < 16; i++) sres[i] -= S[(c0 + i) * DP + c0 + k] * x[k];
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) Wd[b * 16 * WDP + k * WDP + lane] = x[k];
         }
     }
 }

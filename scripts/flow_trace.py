@@ -23,6 +23,15 @@ assert rc == 0, rc
 flops = n ** 3 / 3.0
 print(f"n={n} nb={nb} tasks={nt.value} ms per factorisation: {np.round(ms, 3)}  best {flops / ms.min() / 1e9:.1f} TFLOP/s  median {flops / np.median(ms) / 1e9:.1f}")
 if want_trace and nt.value:
+    ct = tr[nt.value * 8: (nt.value + nb) * 8].reshape(-1, 8)
+    if ct[:, 0].any():      # chain kernel: per block column potrf start, factor done, operands there, solve done, update done
+        cu = (ct[:, :8] - ct[0, 0]) / 100.0
+        per = np.diff(cu[:, 0])
+        for name, sl in (("columns 1-15", slice(1, 16)), ("middle 16", slice(nb // 2 - 8, nb // 2 + 8)), ("last 16", slice(nb - 18, nb - 2))):
+            print(f"chain workgroup {name}: period {per[sl].mean():.1f} us = potrf {(cu[:, 1] - cu[:, 0])[sl].mean():.1f} + wait for the two tiles {(cu[:, 2] - cu[:, 1])[sl].mean():.1f}"
+                  f" + load/solve {(cu[:, 3] - cu[:, 2])[sl].mean():.1f} + update {(cu[:, 4] - cu[:, 3])[sl].mean():.1f}"
+                  f"   [potrf: factor {(cu[:, 7] - cu[:, 0])[sl].mean():.1f}, store issue {(cu[:, 1] - cu[:, 7])[sl].mean():.1f}; load/solve: loads+drain {(cu[:, 5] - cu[:, 2])[sl].mean():.1f}, products {(cu[:, 6] - cu[:, 5])[sl].mean():.1f}, store issue {(cu[:, 3] - cu[:, 6])[sl].mean():.1f}]")
+        print("chain: potrf start of every 8th column (us):", np.round(cu[::8, 0]).astype(int))
     t = tr[: nt.value * 8].reshape(-1, 8)
     t0 = t[:, 0].min()
     us = (t[:, :4] - t0) / 100.0

@@ -60,7 +60,7 @@ def _adjust(eng, fp, mode, passes=5):
 
 def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4, monkeypatch):
     """Four independent device paths -- EO-reduced dataflow factorisation (order 15 014), full-order factorisation
-    (18 014), densified MFMA assembly, and the stream-scheduled factorisation (the one orders below 56 block columns
+    (18 014), densified MFMA assembly, and the stream-scheduled factorisation (the one orders below 24 block columns
     take) -- give the same adjustment.  The normal matrix of this scene has a condition
     number of order 1e9 after Jacobi scaling, so a single step agrees to cond * eps (1e-7 of the largest entry) while the
     converged estimates, which are what north_star's 1e-9 speaks about, agree to 1e-10: Newton's iteration corrects the

@@ -57,7 +57,7 @@ def test_dense_spd_solve_and_inverse(n):
 
 @pytest.mark.parametrize("n", [128, 300, 1000, 2100])
 def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
-    """The dataflow Cholesky (csrc/cholflow.hip) is the default from 56 block columns on; forced here on 1, 3, 8 and 17
+    """The dataflow Cholesky (csrc/cholflow.hip) is the default from 24 block columns on; forced here on 1, 3, 8 and 17
     block columns (ragged last block included), against LAPACK."""
     monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
     rng = np.random.default_rng(n + 1)
@@ -504,13 +504,16 @@ def test_fp32_accumulate_contraction_is_measurably_worse(oracle_mod):
     np.testing.assert_allclose(dxs[1], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
 
 
-@pytest.mark.parametrize("factorisation", ["default", "dataflow"])
+@pytest.mark.parametrize("factorisation", ["default", "streams", "dataflow_two_step"])
 def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     """BASELINE config 3 (100 images x 1 000 points, full interior set, 2x2 correlated image points, U = 3 614): one pass
     against the oracle's packed Bunch-Kaufman solve, normal equations included.  At this order (24 block columns after
-    the EO reduction) the default is the stream-scheduled factorisation; the second case forces the dataflow kernel."""
-    if factorisation == "dataflow":
-        monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
+    the EO reduction) the default is the dataflow factorisation in its chain form; the other cases force the
+    stream-scheduled one and the dataflow form with the separate diagonal kernel."""
+    if factorisation == "streams":
+        monkeypatch.setenv("JAICOV_POTRF_LEGACY", "1")
+    if factorisation == "dataflow_two_step":
+        monkeypatch.setenv("JAICOV_FLOW_CHAIN", "0")
     fp = scene.config("cfg3")
     o = oracle_mod.Oracle(fp)
     s2 = fp.sigma2apriori
