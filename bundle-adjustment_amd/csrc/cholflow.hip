@@ -753,8 +753,8 @@ __global__ void flow_probe_set_kernel(int *word) { __hip_atomic_store(word, 1, _
 
 bool DenseSolver::flow_kernels_overlap() {
     static int cached = -1;
+    if (getenv("JAICOV_FLOW_INLINE_DIAG")) return false;                  // force the one-kernel form
     if (cached >= 0) return cached != 0;
-    if (getenv("JAICOV_FLOW_INLINE_DIAG")) return (cached = 0) != 0;      // force the one-kernel form
     int *d = nullptr, h[2] = {0, 0};
     hipStream_t s2 = nullptr;
     bool ok = hipMalloc(&d, 2 * sizeof(int)) == hipSuccess && hipMemset(d, 0, 2 * sizeof(int)) == hipSuccess &&
@@ -776,7 +776,8 @@ hipError_t DenseSolver::flow_init() {
     const int nb = nfact / 128, row_blocks = n / 128;
     if (!dstream) return hipErrorNotSupported;
     // chain form unless kernels cannot run side by side (one-kernel form, diagonal blocks inline) or it is switched off
-    flow_chain = flow_kernels_overlap() && !(getenv("JAICOV_FLOW_CHAIN") && atoi(getenv("JAICOV_FLOW_CHAIN")) == 0);
+    flow_one_kernel = !flow_kernels_overlap();
+    flow_chain = !flow_one_kernel && !(getenv("JAICOV_FLOW_CHAIN") && atoi(getenv("JAICOV_FLOW_CHAIN")) == 0);
     const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1, flow_chain);
     flow_tasks = (int)tasks.size();
     flow_task_host = tasks;
@@ -851,7 +852,7 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     HIPCHK(hipMemsetAsync(flow_flags, 0, flow_words * sizeof(int), stream));
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
     static const int pf = getenv("JAICOV_FLOW_PF") ? atoi(getenv("JAICOV_FLOW_PF")) : 1;   // measured equal (22.7-23.0 ms at order 15104): one step of lead covers the latency
-    if (!flow_kernels_overlap()) {
+    if (flow_one_kernel) {
         // Kernels cannot run side by side here (every dispatch serialised: counter collection, a debugging environment): the
         // diagonal kernel and the tile kernel would wait for each other until the time limit.  ONE kernel, diagonal blocks inline.
         if (!flow_diag_scratch) HIPCHK(hipMalloc(&flow_diag_scratch, (size_t)flow_grid * (128 * DP + 8 * 16 * WDP) * sizeof(double)));

@@ -504,16 +504,18 @@ def test_fp32_accumulate_contraction_is_measurably_worse(oracle_mod):
     np.testing.assert_allclose(dxs[1], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
 
 
-@pytest.mark.parametrize("factorisation", ["default", "streams", "dataflow_two_step"])
+@pytest.mark.parametrize("factorisation", ["default", "streams", "dataflow_two_step", "dataflow_one_kernel"])
 def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     """BASELINE config 3 (100 images x 1 000 points, full interior set, 2x2 correlated image points, U = 3 614): one pass
     against the oracle's packed Bunch-Kaufman solve, normal equations included.  At this order (24 block columns after
     the EO reduction) the default is the dataflow factorisation in its chain form; the other cases force the
-    stream-scheduled one and the dataflow form with the separate diagonal kernel."""
+    stream-scheduled one, the dataflow form with the separate diagonal kernel and the one-kernel form."""
     if factorisation == "streams":
         monkeypatch.setenv("JAICOV_POTRF_LEGACY", "1")
     if factorisation == "dataflow_two_step":
         monkeypatch.setenv("JAICOV_FLOW_CHAIN", "0")
+    if factorisation == "dataflow_one_kernel":          # the form taken when kernels cannot overlap (counter collection)
+        monkeypatch.setenv("JAICOV_FLOW_INLINE_DIAG", "1")
     fp = scene.config("cfg3")
     o = oracle_mod.Oracle(fp)
     s2 = fp.sigma2apriori
