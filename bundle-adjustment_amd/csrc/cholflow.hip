@@ -83,6 +83,7 @@ struct FlowArgs {
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
     int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
     int crit_prio;           // s_setprio level of the tasks on the critical chain; 0 = none
+    int inv_wt;              // chain form: the inverses leave write-through (1) or plainly behind a release (0)
     int crit_span;           // ... which are the tiles (i, j) with i <= j + crit_span
     int *wgstate;            // [grid] where each workgroup is: ticket << 12 | k << 4 | stage (flow_report_stall reads it after a stall)
     long long *ctrace;       // optional [nb][8], chain kernel: potrf start, factor done, operands there, solve done, update done (wall clock)
@@ -649,16 +650,26 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
             diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
             diag_block_inverses(S, Wd, tq);
             __syncthreads();
-            diag_inverse(S, Wd, g.invd + (long)c * 16384, 0, tq);
-            drain_stores();
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            if (g.inv_wt) {
+                diag_inverse<true>(S, Wd, g.invd + (long)c * 16384, 0, tq);      // write-through
                 drain_stores();
-                flow_st(g.done + (long)c * g.fs + c, 1);
-                flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
+                __syncthreads();      // every wave's part has landed; and S may be loaded again
+                if (tid == 64) {
+                    flow_st(g.done + (long)c * g.fs + c, 1);
+                    flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
+                }
+            } else {
+                diag_inverse<false>(S, Wd, g.invd + (long)c * 16384, 0, tq);
+                drain_stores();
+                __syncthreads();
+                if (tid == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    drain_stores();
+                    flow_st(g.done + (long)c * g.fs + c, 1);
+                    flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
+                }
+                __syncthreads();
             }
-            __syncthreads();      // S is loaded again
         }
         return;
     }
@@ -846,6 +857,7 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.ctrace = flow_trace ? flow_trace + 8 * (size_t)flow_tasks : nullptr;
     g.fake_a = getenv("JAICOV_FLOW_FAKE_A") ? atoi(getenv("JAICOV_FLOW_FAKE_A")) : 0;
     g.crit_prio = getenv("JAICOV_FLOW_PRIO") ? atoi(getenv("JAICOV_FLOW_PRIO")) : 1;
+    g.inv_wt = getenv("JAICOV_FLOW_INV_WT") ? atoi(getenv("JAICOV_FLOW_INV_WT")) : 1;
     g.crit_span = getenv("JAICOV_FLOW_PRIO_SPAN") ? atoi(getenv("JAICOV_FLOW_PRIO_SPAN")) : (flow_chain ? 2 : 1);
     g.alive = flow_alive;
     g.seq = ++flow_seq;

@@ -171,6 +171,8 @@ __device__ __forceinline__ void diag_store_factor(const double *S, double *A, lo
 
 // diag_inverse: inv_out <- L^-1 from the factor in S and the diagonal-block inverses in Wd (the strict upper part of S is
 // used as parking space).  inv_out must be zero above the diagonal on entry.
+// WT: the result leaves with write-through stores (every wave then drains, barrier, flag: no cache-wide release needed).
+template <bool WT = false>
 __device__ __forceinline__ void diag_inverse(double *S, const double *Wd, double *inv_out, int dbg, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -215,7 +217,8 @@ __device__ __forceinline__ void diag_inverse(double *S, const double *Wd, double
             v.y = (c + 1 > r) ? 0.0
                               : (((r >> 4) == ((c + 1) >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + ((c + 1) & 15)]
                                                               : S[(c + 1) * DP + r]);
-            *reinterpret_cast<d2_t *>(inv_out + r * 128 + c) = v;
+            if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(inv_out + r * 128 + c), "v"(v) : "memory");
+            else *reinterpret_cast<d2_t *>(inv_out + r * 128 + c) = v;
         }
     }
 }
