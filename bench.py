@@ -232,8 +232,9 @@ def main():
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items()},
             "roofline": {"kernel": ("gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update of the stream-scheduled factorisation, fp64 MFMA 16x16x4)"
                                     if os.environ.get("JAICOV_POTRF_LEGACY") else
-                                    "chol_tile_kernel<1> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
-                                    "persistent launch, fp64 MFMA 16x16x4; algorithmic flops = order^3 / 3; symbol as listed by rocprofv3)"),
+                                    "chol_tile_kernel<1, false> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
+                                    "persistent launch, fp64 MFMA 16x16x4, with potrf_chain_kernel's two workgroups beside it for the diagonal "
+                                    "blocks; algorithmic flops = order^3 / 3; symbols as listed by rocprofv3)"),
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "launches": ks["launches"], "avg_launch_ms": ks["ms"] / max(ks["launches"], 1),

@@ -31,4 +31,7 @@ for kind in ("fetch", "write"):
                 w.writerow([r["Dispatch_Id"], r["Kernel_Name"][:90], r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],
                             r["Counter_Name"], r["Counter_Value"]])
 shutil.copy(os.path.join(O, f"pmc_traffic_{tag}.json"), os.path.join(P, f"{name}_pmc", "pmc_traffic.json")) if os.path.exists(os.path.join(O, f"pmc_traffic_{tag}.json")) else None
+src = os.path.join(O, f"pmc_traffic_{tag}.json")
+if os.path.exists(src):
+    shutil.copy(src, os.path.join(P, "pmc_traffic.json"))      # the file bench.py reads its `traffic` from
 print("collected", name)
