@@ -507,8 +507,8 @@ def test_fp32_accumulate_contraction_is_measurably_worse(oracle_mod):
 @pytest.mark.parametrize("factorisation", ["default", "streams", "dataflow_two_step", "dataflow_one_kernel"])
 def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     """BASELINE config 3 (100 images x 1 000 points, full interior set, 2x2 correlated image points, U = 3 614): one pass
-    against the oracle's packed Bunch-Kaufman solve, normal equations included.  At this order (24 block columns after
-    the EO reduction) the default is the dataflow factorisation in its chain form; the other cases force the
+    against the oracle's packed Bunch-Kaufman solve, normal equations included.  At this order (29 block
+    columns) the default is the dataflow factorisation in its chain form; the other cases force the
     stream-scheduled one, the dataflow form with the separate diagonal kernel and the one-kernel form."""
     if factorisation == "streams":
         monkeypatch.setenv("JAICOV_POTRF_LEGACY", "1")
