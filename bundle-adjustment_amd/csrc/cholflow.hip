@@ -83,6 +83,7 @@ struct FlowArgs {
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
     int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
     int crit_prio;           // s_setprio level of the tasks on the critical chain; 0 = none
+    int second_update;       // chain form: workgroup 2 also subtracts its tile from tile (c+2, c+1)
     int inv_wt;              // chain form: the inverses leave write-through (1) or plainly behind a release (0)
     int crit_span;           // ... which are the tiles (i, j) with i <= j + crit_span
     int *wgstate;            // [grid] where each workgroup is: ticket << 12 | k << 4 | stage (flow_report_stall reads it after a stall)
@@ -98,8 +99,16 @@ __device__ __forceinline__ void store_wt(double *p, double v) {   // write-throu
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void store_wt2(double *p, d2_t v) {   // the same for 16 bytes (no builtin for a 16-byte atomic store)
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+// The same for 16 bytes (no builtin for a 16-byte atomic store).  The compiler does not know that this asm is a vector-memory
+// store, so it inserts none of the wait states such a store needs:
+//   after it: a store of more than 8 bytes reads the upper half of its data registers a few cycles after issue; a VALU
+//     instruction that overwrites them right behind the store (the register allocator reuses them at once) changes what is
+//     stored.  Seen exactly so: the second double of some 16-byte pieces of L[c+2][c] wrong, lanes 12-15 of every 16, last block
+//     column only (where the stores follow each other most densely).  `s_nop 1` = the two wait states LLVM inserts for real stores.
+//   before it: a register written by an MFMA needs 18+ wait states before a memory instruction may read it (no interlock);
+//     the data usually come through v_accvgpr_read (a VALU instruction the compiler handles), but nothing guarantees that.
+__device__ __forceinline__ void store_wt2(double *p, d2_t v) {
+    asm volatile("s_nop 15\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -367,10 +376,17 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                         if (spins > 0) waited += wall_clock64() - t0;
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         drain_stores();
-                        if (lane == 0) s_msg[1] = cnt;
+                        if (lane == 0) {
+                            s_msg[1] = cnt;
+                            s_msg[2] = spins;
+                        }
                     }
                     __syncthreads();
                     const int cnt = s_msg[1];
+                    // a task that had to wait for an operand is at the dependency front: what it does next (this block column,
+                    // then the product with the inverse) is what the tiles to its right are waiting for -- it takes the matrix
+                    // pipe ahead of the workgroup it shares the CU with, which is (usually) still deep in its own updates
+                    if (g.crit_prio >= 2 && s_msg[2] > 0) __builtin_amdgcn_s_setprio(3);
                     __syncthreads();
                     if (cnt == 0) { ok = false; break; }
                     ++n_runs;
@@ -440,7 +456,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             }
             break;
         }
-        if (critical) __builtin_amdgcn_s_setprio(0);
+        if (g.crit_prio > 0) __builtin_amdgcn_s_setprio(0);
         FLOW_STAGE_MARK(k, ok ? 7 : 8);
         if (!ok) break;
         if (g.trace && tid == 0) {
@@ -541,6 +557,42 @@ __device__ __forceinline__ void chain_tile_store(double *Tg, long ld, const d4_t
             store_wt2(tp + (long)(16 * cc) * ld + 16 * p, lo);
             store_wt2(tp + (long)(16 * cc) * ld + 16 * p + 2, hi);
         }
+}
+
+// t -= (tile in S) y, all in the transposed layout of chain_tile_load: for a tile T = t', A = y' and the 128 x 128 tile B in S
+// (row-major, stride DP) this is T -= A B'.  512 MFMAs per wave.
+__device__ __forceinline__ void chain_tile_update(d4_t (&t)[8][2], const d4_t (&y)[8][2], const double *S, const int tid) {
+    const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+    const int pi15 = 4 * (l15 & 3) + (l15 >> 2);
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+#pragma unroll
+        for (int p = 0; p < 8; p++)
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const double av = -S[(16 * p + pi15) * DP + 16 * q + 4 * l4 + ks];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) t[p][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, y[q][cc][ks], t[p][cc], 0, 0, 0);
+            }
+}
+// a whole 128 x 128 tile -> S (row-major, stride DP)
+__device__ __forceinline__ void chain_tile_to_lds(const double *A, long ld, double *S, const int tid) {
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        d2_t buf[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx2 = tid + 256 * (16 * half + i);
+            buf[i] = *reinterpret_cast<const d2_t *>(A + (long)(idx2 >> 6) * ld + 2 * (idx2 & 63));
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int idx2 = tid + 256 * (16 * half + i);
+            const int r = idx2 >> 6, c = 2 * (idx2 & 63);
+            S[r * DP + c] = buf[i].x;
+            S[r * DP + c + 1] = buf[i].y;
+        }
+    }
 }
 
 // One link of the chain after potrf(c): S holds L_cc, Wd the inverses of its 16x16 diagonal blocks; tile (c+1, c) and the
@@ -673,6 +725,73 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
         }
         return;
     }
+    if (blockIdx.x == 2) {
+        // ---- the second subdiagonal: workgroup 2 finishes tile (c+2, c) by the same block forward substitution as the chain
+        //      (from L_cc itself: it does not wait for the inverse) and subtracts it from tile (c+2, c+1), the tile the chain
+        //      workgroup needs next -- the path that used to take three tile workgroups in a row (inverse -> product with
+        //      the inverse -> update) and set the period of the chain.
+        for (int c = 0; c + 2 < g.nb; c++) {
+            if (tid == 0) {
+                const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                drain_stores();
+                s_ok = r ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_ok == 0) return;
+            __syncthreads();
+            d4_t y[8][2];
+            {
+                FLOW_OPAQUE_TID(tq);
+                diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
+                diag_block_inverses(S, Wd, tq);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c, c + 1, g.ctrl, g.timeout, nullptr);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                drain_stores();
+                s_ok = r ? 1 : 0;
+            }
+            __syncthreads();       // also: Wd is complete
+            if (s_ok == 0) return;
+            __syncthreads();
+            double *T2 = g.L + (long)(c + 2) * 128 * g.ld + (long)c * 128;      // tile (c+2, c)
+            {
+                FLOW_OPAQUE_TID(tq);
+                chain_tile_load(T2, g.ld, y, tq);
+                chain_tile_solve(y, S, Wd, tq);
+                chain_tile_store(T2, g.ld, y, tq);
+            }
+            drain_stores();
+            __syncthreads();       // L[c+2][c] has landed; every wave has read L_cc for the last time
+            if (tid == 64) flow_st(g.done + (long)(c + 2) * g.fs + c, 1);
+            if (!g.second_update) continue;
+            if (tid == 0) {
+                bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c + 1, c + 1, g.ctrl, g.timeout, nullptr);
+                r = r && flow_spin(g.done + (long)(c + 1) * g.fs + c, 1, g.ctrl, g.timeout, nullptr);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                drain_stores();
+                s_ok = r ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_ok == 0) return;
+            __syncthreads();
+            {
+                FLOW_OPAQUE_TID(tq);
+                d4_t t[8][2];
+                chain_tile_to_lds(g.L + (long)(c + 1) * 128 * g.ld + (long)c * 128, g.ld, S, tq);      // L[c+1][c]
+                chain_tile_load(T2 + 128, g.ld, t, tq);                                                 // tile (c+2, c+1)
+                __syncthreads();
+                chain_tile_update(t, y, S, tq);
+                chain_tile_store(T2 + 128, g.ld, t, tq);
+            }
+            drain_stores();
+            __syncthreads();
+            if (tid == 64) flow_st(g.applied + (long)(c + 2) * g.fs + c + 1, c + 2);
+        }
+        return;
+    }
     // ---- the chain -------------------------------------------------------------------------------------------------
     if (tid == 0) {
         const bool r = flow_spin(g.applied, 1, g.ctrl, g.timeout, nullptr);      // tile (0, 0): scaled, in L
@@ -727,15 +846,17 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
 // columns; the tiles of the group's diagonal blocks first, then row by row the w tiles of a row, which stream the same A
 // strip L[i][0..j) at the same time (the second reader finds it in L2 / the Infinity Cache).  Either way a tile only depends
 // on tiles that come earlier in the list.
-static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain) {
+static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain, int second) {
     std::vector<int4> tasks;
     tasks.reserve((size_t)nb * (row_blocks + 1) / 2 + row_blocks);
     if (w < 1) w = 1;
     // chain form (potrf_chain_kernel): the diagonal tile (j, j) is visited for the block columns < j - 1 only and the tile below
-    // it, (j + 1, j), is not finished: the chain workgroup takes both from there
+    // it, (j + 1, j), is not finished: the chain workgroup takes both from there.  With the optional third workgroup
+    // (`second` = 1 / 2) the tile (j + 2, j) is not finished either, and (2) the tile (j + 1, j) lacks its last update.
     auto task = [&](int i, int j) {
         if (chain && i == j) return make_int4(i, j, 0, std::max(j - 1, 0));
-        if (chain && i == j + 1 && i < nb) return make_int4(i, j, 0, j);
+        if (chain && i == j + 1 && i < nb) return make_int4(i, j, 0, second >= 2 ? std::max(j - 1, 0) : j);   // second = 2: the last update comes from workgroup 2
+        if (chain && second >= 1 && i == j + 2 && i < nb) return make_int4(i, j, 0, j);     // all updates; workgroup 2 finishes it
         return make_int4(i, j, 0, j | FLOW_FIN);
     };
     for (int j0 = 0; j0 < nb; j0 += w) {
@@ -789,7 +910,11 @@ hipError_t DenseSolver::flow_init() {
     // chain form unless kernels cannot run side by side (one-kernel form, diagonal blocks inline) or it is switched off
     flow_one_kernel = !flow_kernels_overlap();
     flow_chain = !flow_one_kernel && !(getenv("JAICOV_FLOW_CHAIN") && atoi(getenv("JAICOV_FLOW_CHAIN")) == 0);
-    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1, flow_chain);
+    // third chain workgroup for the second subdiagonal: 0 = none (default: measured equal, 22.4 ms at order 15 104, because the
+    // tiles it needs are themselves late by the same path one diagonal further out), 1 = it finishes tile (c+2, c), 2 = and
+    // subtracts it from tile (c+2, c+1)
+    flow_second = flow_chain && getenv("JAICOV_FLOW_SECOND") ? std::min(std::max(atoi(getenv("JAICOV_FLOW_SECOND")), 0), 2) : 0;
+    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1, flow_chain, flow_second);
     flow_tasks = (int)tasks.size();
     flow_task_host = tasks;
     HIPCHK(hipMalloc(&flow_task_list, tasks.size() * sizeof(int4)));
@@ -808,8 +933,8 @@ hipError_t DenseSolver::flow_init() {
     if (flow_grid > 1024) flow_grid = 1024;
     HIPCHK(hipMalloc(&flow_scratch, ((size_t)flow_grid * 16384 + 64) * sizeof(double)));
     HIPCHK(hipMemset(flow_scratch + (size_t)flow_grid * 16384, 0, 64 * sizeof(double)));
-    HIPCHK(hipHostMalloc((void **)&flow_alive, 2 * sizeof(int), hipHostMallocMapped));
-    flow_alive[0] = flow_alive[1] = 0;
+    HIPCHK(hipHostMalloc((void **)&flow_alive, 4 * sizeof(int), hipHostMallocMapped));
+    flow_alive[0] = flow_alive[1] = flow_alive[2] = flow_alive[3] = 0;
     HIPCHK(hipEventCreateWithFlags(&flow_e0, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e1, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e2, hipEventDisableTiming));
@@ -857,6 +982,7 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.ctrace = flow_trace ? flow_trace + 8 * (size_t)flow_tasks : nullptr;
     g.fake_a = getenv("JAICOV_FLOW_FAKE_A") ? atoi(getenv("JAICOV_FLOW_FAKE_A")) : 0;
     g.crit_prio = getenv("JAICOV_FLOW_PRIO") ? atoi(getenv("JAICOV_FLOW_PRIO")) : 1;
+    g.second_update = flow_second >= 2 ? 1 : 0;
     g.inv_wt = getenv("JAICOV_FLOW_INV_WT") ? atoi(getenv("JAICOV_FLOW_INV_WT")) : 1;
     g.crit_span = getenv("JAICOV_FLOW_PRIO_SPAN") ? atoi(getenv("JAICOV_FLOW_PRIO_SPAN")) : (flow_chain ? 2 : 1);
     g.alive = flow_alive;
@@ -882,7 +1008,7 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     HIPCHK(hipEventRecord(flow_e0, stream));
     HIPCHK(hipStreamWaitEvent(dstream, flow_e0, 0));
     if (all_ready) HIPCHK(hipStreamWaitEvent(dstream, all_ready, 0));
-    if (flow_chain) hipLaunchKernelGGL(potrf_chain_kernel, dim3(2), dim3(256), 0, dstream, g);
+    if (flow_chain) hipLaunchKernelGGL(potrf_chain_kernel, dim3(flow_second ? 3 : 2), dim3(256), 0, dstream, g);
     else hipLaunchKernelGGL(potrf_diag_chain_kernel, dim3(1), dim3(256), 0, dstream, g);
     HIPCHK(hipGetLastError());
     // Residency.  The diagonal kernel needs a whole CU's LDS and runs on the stream whose CU mask holds one CU of every XCD.
@@ -894,7 +1020,9 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     {
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
-        while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq || (flow_chain && __atomic_load_n(flow_alive + 1, __ATOMIC_ACQUIRE) != g.seq)) {
+        while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq ||
+               (flow_chain && (__atomic_load_n(flow_alive + 1, __ATOMIC_ACQUIRE) != g.seq ||
+                               (flow_second && __atomic_load_n(flow_alive + 2, __ATOMIC_ACQUIRE) != g.seq)))) {
             if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
                 return hipErrorLaunchTimeOut;
         }

@@ -84,7 +84,13 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__re
                 for (int i = 0; i < 4; i++) {
                     b[i] = 0;
                     if (sq + 2 * i < nrhs) {
-                        b[i] = __hip_atomic_load(xp + (long)(sq + 2 * i) * xs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // every 1024th poll by a read-modify-write at agent scope: never served from a stale line of this
+                        // XCD's L2 (cholflow.hip, "Visibility": plain polls were seen to miss a set flag about once in 300
+                        // factorisations)
+                        const unsigned long long *q = xp + (long)(sq + 2 * i) * xs;
+                        b[i] = (spin & 1023) == 1023
+                                   ? __hip_atomic_fetch_or(const_cast<unsigned long long *>(q), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                   : __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ready = ready && b[i] != BS_UNSET;
                     }
                 }

@@ -1604,6 +1604,32 @@ extern "C" int jaicov_debug_potrf_bench(int n, int reps, double *ms_out, long lo
     return status;
 }
 
+// debug: factor a host matrix (n x n row-major, lower part used, n a multiple of 128) with DenseSolver::potrf and return the
+// factor (lower part, row-major n x n) -- scripts/flow_small_check.py compares it tile by tile with LAPACK
+extern "C" int jaicov_debug_potrf_factor(int n, const double *A, double *L_out) {
+    std::string err;
+    if (check_device(err)) return JAICOV_ERR_NO_DEVICE;
+    if (n <= 0 || n % 128 || !A || !L_out) return JAICOV_ERR_BAD_ARGUMENT;
+    hipStream_t s;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return JAICOV_ERR_DEVICE;
+    DenseSolver ds;
+    int status = JAICOV_OK;
+    do {
+        if (ds.init(s, n, false, true) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
+        hipLaunchKernelGGL(fill_spd_kernel, dim3((ds.n + 255) / 256, ds.n), dim3(256), 0, s, ds.L, ds.ld, ds.n, n);   // incl. the right-hand-side rows
+        if (hipMemcpy2DAsync(ds.L, ds.ld * sizeof(double), A, (size_t)n * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyHostToDevice, s) != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
+        if (ds.potrf() != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
+        const int info = ds.fetch_info();
+        if (info < 0) { status = JAICOV_ERR_DEVICE; break; }
+        if (info > 0) { status = JAICOV_ERR_SINGULAR; break; }
+        if (hipMemcpy2DAsync(L_out, (size_t)n * sizeof(double), ds.L, ds.ld * sizeof(double), (size_t)n * sizeof(double), n, hipMemcpyDeviceToHost, s) != hipSuccess) status = JAICOV_ERR_DEVICE;
+    } while (0);
+    hipStreamSynchronize(s);
+    ds.release();
+    hipStreamDestroy(s);
+    return status;
+}
+
 // C (M x N row-major) = alpha * op(A) op(B) + beta * C on the device, host buffers in/out (kernel parity + timing)
 extern "C" int jaicov_dense_gemm(int32_t alay, int32_t blay, int32_t M, int32_t N, int32_t K, double alpha, const double *A,
                                  int64_t lda, const double *B, int64_t ldb, double beta, double *C, int64_t ldc,

@@ -217,7 +217,9 @@ __device__ __forceinline__ void diag_inverse(double *S, const double *Wd, double
             v.y = (c + 1 > r) ? 0.0
                               : (((r >> 4) == ((c + 1) >> 4)) ? Wd[(r >> 4) * 16 * WDP + (r & 15) * WDP + ((c + 1) & 15)]
                                                               : S[(c + 1) * DP + r]);
-            if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(inv_out + r * 128 + c), "v"(v) : "memory");
+            // (s_nop 1: the compiler does not know this is a store and would let the next instruction reuse the data registers
+            // while the store still reads their upper half -- cholflow.hip, store_wt2)
+            if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(inv_out + r * 128 + c), "v"(v) : "memory");
             else *reinterpret_cast<d2_t *>(inv_out + r * 128 + c) = v;
         }
     }

@@ -73,6 +73,27 @@ def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
     assert ei.value.code == 1
 
 
+@pytest.mark.parametrize("form", ["chain", "chain_second_1", "chain_second_2", "two_step", "one_kernel", "streams"])
+@pytest.mark.parametrize("n", [384, 1152])
+def test_factor_tile_by_tile(n, form, monkeypatch):
+    """The Cholesky factor itself, every 128 x 128 tile against LAPACK, under every form of the factorisation (the chain
+    form's workgroups each own particular tiles: a solve / inverse check alone can hide which one is wrong)."""
+    import ctypes as C
+    monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
+    for k, v in {"chain_second_1": ("JAICOV_FLOW_SECOND", "1"), "chain_second_2": ("JAICOV_FLOW_SECOND", "2"), "two_step": ("JAICOV_FLOW_CHAIN", "0"),
+                 "one_kernel": ("JAICOV_FLOW_INLINE_DIAG", "1"), "streams": ("JAICOV_POTRF_LEGACY", "1")}.items():
+        if form == k:
+            monkeypatch.setenv(*v)
+    lib = engine.load_library()
+    lib.jaicov_debug_potrf_factor.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, n + 20))
+    S = np.ascontiguousarray(G @ G.T / n + np.eye(n))
+    out = np.zeros((n, n))
+    assert lib.jaicov_debug_potrf_factor(n, S.ctypes.data, out.ctypes.data) == 0
+    np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-12)
+
+
 def test_dense_not_spd_reports_singular():
     S = -np.eye(130)
     with pytest.raises(engine.EngineError) as ei:
