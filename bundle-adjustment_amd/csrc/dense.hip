@@ -38,11 +38,27 @@ __global__ __launch_bounds__(256) void potrf_diag_kernel(double *A, long ld, dou
 constexpr unsigned long long BS_UNSET = ~0ull;
 constexpr int BS_SPIN_MAX = 1 << 22;
 
+// NR = right-hand sides carried (1, 2, 4 or 8: the smallest that holds nrhs; an adjustment without datum defect has ONE,
+// and the 8-wide form spent 2 of its 8 us per link of the chain on seven columns of zeros)
+template <int NR>
+__device__ __forceinline__ void bs_row(const double *p, double (&v)[NR]) {
+    if constexpr (NR % 4 == 0) {
+#pragma unroll
+        for (int h = 0; h < NR / 4; h++) {
+            const d4_t t = *reinterpret_cast<const d4_t *>(p + 4 * h);
+            v[4 * h] = t[0]; v[4 * h + 1] = t[1]; v[4 * h + 2] = t[2]; v[4 * h + 3] = t[3];
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NR; q++) v[q] = p[q];
+    }
+}
+template <int NR>
 __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__restrict__ L, long ld,
                                                               const double *__restrict__ invd, const double *__restrict__ Z,
                                                               long zs, double *X, long xs, int nb, int nrhs) {
-    __shared__ __attribute__((aligned(16))) double xj[2][128][DENSE_MAX_RHS];     // x_j (then v_k), [row][rhs]
-    __shared__ __attribute__((aligned(16))) double red[4][128][DENSE_MAX_RHS];    // partial sums
+    __shared__ __attribute__((aligned(32))) double xj[2][128][NR];     // x_j (then v_k), [row][rhs]
+    __shared__ __attribute__((aligned(32))) double red[4][128][NR];    // partial sums
     const int tid = threadIdx.x;
     const int k = nb - 1 - (int)blockIdx.x;
     const int c2 = tid & 63, qd = tid >> 6;        // block phase: columns 2*c2, 2*c2+1; rows 32*qd .. 32*qd+31
@@ -55,11 +71,11 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__re
 #pragma unroll
         for (int r = 0; r < 64; r++) dinv[r] = w[(long)r * 128];
 #pragma unroll
-        for (int i = 0; i < 4; i++) zk[i] = sq + 2 * i < nrhs ? Z[(long)(sq + 2 * i) * zs + k * 128 + sr] : 0.0;
+        for (int i = 0; i < 4; i++) zk[i] = sq + 2 * i < nrhs ? Z[(long)(sq + 2 * i) * zs + k * 128 + sr] : 0.0;   // nrhs <= NR
     }
-    double acc[2][DENSE_MAX_RHS];
+    double acc[2][NR];
 #pragma unroll
-    for (int q = 0; q < DENSE_MAX_RHS; q++) acc[0][q] = acc[1][q] = 0.0;
+    for (int q = 0; q < NR; q++) acc[0][q] = acc[1][q] = 0.0;
     d2_t blk[32], nblk[32];
     int j = nb - 1;
     if (j > k) {
@@ -97,26 +113,25 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__re
                 if (!ready) __builtin_amdgcn_s_sleep(2);
             } while (!ready && ++spin < BS_SPIN_MAX);
 #pragma unroll
-            for (int i = 0; i < 4; i++) xj[j & 1][sr][sq + 2 * i] = __longlong_as_double((long long)b[i]);
+            for (int i = 0; i < 4; i++)
+                if (sq + 2 * i < NR) xj[j & 1][sr][sq + 2 * i] = __longlong_as_double((long long)b[i]);
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 32; r++) {
-            const d4_t x0 = *reinterpret_cast<const d4_t *>(&xj[j & 1][32 * qd + r][0]);
-            const d4_t x1 = *reinterpret_cast<const d4_t *>(&xj[j & 1][32 * qd + r][4]);
+            double xv[NR];
+            bs_row<NR>(&xj[j & 1][32 * qd + r][0], xv);
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                acc[0][q] += blk[r].x * x0[q];
-                acc[1][q] += blk[r].y * x0[q];
-                acc[0][4 + q] += blk[r].x * x1[q];
-                acc[1][4 + q] += blk[r].y * x1[q];
+            for (int q = 0; q < NR; q++) {
+                acc[0][q] += blk[r].x * xv[q];
+                acc[1][q] += blk[r].y * xv[q];
             }
         }
 #pragma unroll
         for (int r = 0; r < 32; r++) blk[r] = nblk[r];
     }
 #pragma unroll
-    for (int q = 0; q < DENSE_MAX_RHS; q++) {
+    for (int q = 0; q < NR; q++) {
         red[qd][2 * c2][q] = acc[0][q];
         red[qd][2 * c2 + 1][q] = acc[1][q];
     }
@@ -124,32 +139,29 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__re
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const int q = sq + 2 * i;
-        xj[0][sr][q] = zk[i] - (red[0][sr][q] + red[1][sr][q] + red[2][sr][q] + red[3][sr][q]);
+        if (q < NR) xj[0][sr][q] = zk[i] - (red[0][sr][q] + red[1][sr][q] + red[2][sr][q] + red[3][sr][q]);
     }
     __syncthreads();
     // x_k[di] = sum_r W[r][di] v[r]
-    double out[DENSE_MAX_RHS];
+    double out[NR];
 #pragma unroll
-    for (int q = 0; q < DENSE_MAX_RHS; q++) out[q] = 0.0;
+    for (int q = 0; q < NR; q++) out[q] = 0.0;
 #pragma unroll
     for (int r = 0; r < 64; r++) {
-        const d4_t v0 = *reinterpret_cast<const d4_t *>(&xj[0][64 * dh + r][0]);
-        const d4_t v1 = *reinterpret_cast<const d4_t *>(&xj[0][64 * dh + r][4]);
+        double vv[NR];
+        bs_row<NR>(&xj[0][64 * dh + r][0], vv);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            out[q] += dinv[r] * v0[q];
-            out[4 + q] += dinv[r] * v1[q];
-        }
+        for (int q = 0; q < NR; q++) out[q] += dinv[r] * vv[q];
     }
     if (dh == 1) {
 #pragma unroll
-        for (int q = 0; q < DENSE_MAX_RHS; q++) red[0][di][q] = out[q];
+        for (int q = 0; q < NR; q++) red[0][di][q] = out[q];
     }
     __syncthreads();
     if (dh == 0) {
         unsigned long long *xp = reinterpret_cast<unsigned long long *>(X) + k * 128 + di;
 #pragma unroll
-        for (int q = 0; q < DENSE_MAX_RHS; q++) {
+        for (int q = 0; q < NR; q++) {
             if (q >= nrhs) break;
             unsigned long long bits = (unsigned long long)__double_as_longlong(out[q] + red[0][di][q]);
             if (bits == BS_UNSET) bits = 0x7FF8000000000000ull;
@@ -534,7 +546,10 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     if (!aug || nrhs < 1 || nrhs > DENSE_MAX_RHS) return hipErrorInvalidValue;
     const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nrhs * xs * sizeof(double), stream));   // "not yet published"
-    hipLaunchKernelGGL(backsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
+    if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
+    else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
+    else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
+    else hipLaunchKernelGGL(backsolve_chain_kernel<8>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
     return hipGetLastError();
 }
 
