@@ -869,6 +869,19 @@ static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain
     return tasks;
 }
 
+}  // namespace jaicov
+// debug / tests (no device needed): the task list of the dataflow factorisation, 4 ints per task {i, j, k0, k1 | FIN << 20};
+// returns the number of tasks (the first `cap` are written)
+extern "C" int jaicov_debug_flow_tasks(int nb, int row_blocks, int w, int chain, int second, int *out, int cap) {
+    if (nb < 1 || row_blocks < nb) return -1;
+    const std::vector<int4> t = jaicov::flow_schedule(nb, row_blocks, w, chain != 0, second);
+    for (size_t q = 0; q < t.size() && (int)q < cap; q++) {
+        out[4 * q] = t[q].x; out[4 * q + 1] = t[q].y; out[4 * q + 2] = t[q].z; out[4 * q + 3] = t[q].w;
+    }
+    return (int)t.size();
+}
+namespace jaicov {
+
 // Can two kernels of this process run at the same time?  Probed once: a kernel that waits (at most 50 ms) for a word that a
 // second kernel on another stream sets.  Under rocprofv3 --pmc (every dispatch serialised) the second one only starts after
 // the first has given up.
