@@ -49,7 +49,7 @@ namespace jaicov {
     } while (0)
 
 // control words
-enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CHAIN_AT = 3, FLOW_STALE = 4, FLOW_STALE_CONFIRMED = 5, FLOW_CTRL_WORDS = 16 };   // CHAIN_AT: column << 4 | stage of the chain workgroup
+enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CHAIN_AT = 3, FLOW_STALE = 4, FLOW_STALE_CONFIRMED = 5, FLOW_RESCUED = 6, FLOW_CTRL_WORDS = 16 };   // RESCUED: hits of the read-modify-write poll after > 1 ms of waiting   // CHAIN_AT: column << 4 | stage of the chain workgroup
 constexpr int FLOW_FIN = 1 << 20;        // task.w = k1 | FLOW_FIN: finish the tile after the updates
 constexpr int FLOW_LDS = 144;            // LDS row stride of both operands (gemm_f64.h: == 16 mod 32 doubles)
 constexpr int FLOW_STAGE = GEMM_BK * 2 * FLOW_LDS;
@@ -94,7 +94,10 @@ struct FlowArgs {
 __device__ __forceinline__ int flow_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // the same word read by a read-modify-write at agent scope: performed where all XCDs agree (never served from an L2 line)
 __device__ __forceinline__ int flow_ld_rmw(const int *p) { return __hip_atomic_fetch_or(const_cast<int *>(p), 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flow_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// flags are stored at SYSTEM scope (sc0 sc1: past every cache of the device) and the fallback poll reads them the same way:
+// see "Visibility" -- polls were seen not to find flags that memory held as set, with agent-scope stores and polls
+__device__ __forceinline__ void flow_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ int flow_ld_sys(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void store_wt(double *p, double v) {   // write-through (sc1) store of one double
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
@@ -126,9 +129,10 @@ __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, 
         else {
             __builtin_amdgcn_s_sleep(40);
             if ((spins & 31) == 0) {
-                if (flow_ld_rmw(flag) >= want) {      // set; did the plain poll only just miss it, or does it still not see it?
+                if (flow_ld_sys(flag) >= want || flow_ld_rmw(flag) >= want) {      // set; did the plain poll only just miss it, or does it still not see it?
                     atomicAdd(ctrl + FLOW_STALE, 1);
                     if (flow_ld(flag) < want) atomicAdd(ctrl + FLOW_STALE_CONFIRMED, 1);
+                    if (wall_clock64() - t0 > 100000) atomicAdd(ctrl + FLOW_RESCUED, 1);
                     break;
                 }
                 if (flow_ld(ctrl + FLOW_ABORT) != 0) { ok = false; break; }
@@ -356,7 +360,12 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                             else {
                                 __builtin_amdgcn_s_sleep(40);
                                 if ((spins & 31) == 0) {
-                                    const bool ready2 = idx < k1 && flow_ld_rmw(fi + idx) != 0 && flow_ld_rmw(fj + idx) != 0;
+                                    if (wall_clock64() - t0 > 100000) {       // > 1 ms: whatever this CU / XCD still holds of the flag lines goes
+                                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                                        drain_stores();
+                                    }
+                                    const bool ready2 = idx < k1 && (flow_ld_sys(fi + idx) != 0 || flow_ld_rmw(fi + idx) != 0) &&
+                                                        (flow_ld_sys(fj + idx) != 0 || flow_ld_rmw(fj + idx) != 0);
                                     const unsigned long long m2 = __ballot(ready2);
                                     cnt = m2 == ~0ull ? 64 : __builtin_ctzll(~m2);
                                     if (cnt > 0) {
@@ -365,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                                         if (lane == 0) {
                                             atomicAdd(g.ctrl + FLOW_STALE, 1);
                                             if ((m3 & 1ull) == 0) atomicAdd(g.ctrl + FLOW_STALE_CONFIRMED, 1);   // the plain poll still misses it
+                                            if (wall_clock64() - t0 > 100000) atomicAdd(g.ctrl + FLOW_RESCUED, 1);   // ... had missed it for > 1 ms
                                         }
                                         break;
                                     }
@@ -988,7 +998,9 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.info = d_info;
     g.scratch = flow_scratch;
     g.zeros = flow_scratch + (size_t)flow_grid * 16384;
-    g.timeout = 100000000LL * (getenv("JAICOV_FLOW_TIMEOUT_S") ? atoi(getenv("JAICOV_FLOW_TIMEOUT_S")) : 10);
+    // time limit of a single wait, 100 MHz ticks: 0.5 s (a whole factorisation takes 0.7-40 ms; the longest ordinary wait ~2 ms)
+    g.timeout = getenv("JAICOV_FLOW_TIMEOUT_S") ? 100000000LL * atoi(getenv("JAICOV_FLOW_TIMEOUT_S"))
+                                                 : 100000LL * (getenv("JAICOV_FLOW_TIMEOUT_MS") ? atoi(getenv("JAICOV_FLOW_TIMEOUT_MS")) : 500);
     g.src = flow_src; g.src_ld = flow_src_ld; g.V = flow_V; g.Bh = flow_Bh; g.d = flow_d; g.U = flow_U; g.bstride = flow_bstride;
     flow_src = nullptr;      // one factorisation only
     g.trace = flow_trace;

@@ -634,7 +634,9 @@ int DenseSolver::fetch_info() {
     const int ab = cw[1];
     flow_stale_events += cw[4];
     flow_stale_confirmed += cw[5];
-    if (cw[4] && getenv("JAICOV_VERBOSE")) fprintf(stderr, "jaicov: dataflow factorisation: %d flag(s) found by the read-modify-write poll, %d of them still invisible to the plain poll\n", cw[4], cw[5]);
+    flow_rescued += cw[6];
+    if (cw[4] && getenv("JAICOV_VERBOSE"))
+        fprintf(stderr, "jaicov: dataflow factorisation: %d flag(s) found by the read-modify-write poll, %d of them still invisible to the plain poll, %d after more than 1 ms of waiting\n", cw[4], cw[5], cw[6]);
     if (ab != 0) {            // a wait of the dataflow factorisation ran into its time limit
         flow_report_stall();
         return -9;

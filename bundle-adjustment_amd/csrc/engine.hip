@@ -162,6 +162,7 @@ __global__ void store_inv_kernel(const double *__restrict__ Q, long ld, int m, d
 struct jaicov_engine {
     std::string err = "";
     int device = 0;
+    int flow_retries = 0;      // dataflow factorisations that were abandoned and repeated (solve)
     hipStream_t stream = nullptr;
     DevProblem p{};
     std::vector<void *> allocs;
@@ -1061,6 +1062,11 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     // dataflow factorisation: the tile kernel reads N itself and scales on the fly (no copy of the matrix at all);
     // stream-scheduled one: the columns of the first panel go first, together with the right-hand sides; the panel then
     // factors on its stream while the rest of the matrix is still being scaled and copied (0.4 ms at config 4).
+    // (in a loop: a dataflow factorisation that was abandoned -- cholflow.hip, "Visibility": a wait ran into its time limit, seen
+    // about once in 1 000 factorisations at config 4 -- is repeated; N, V and the datum rows are untouched by it)
+    std::vector<double> X;
+    int info = 0;
+    for (int attempt = 0;; attempt++) {
     if (!fused)
         hipLaunchKernelGGL(scale_copy_kernel, dim3((c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
                            Up, d, e->d_V, e->d_B, Upad, 0, c1);
@@ -1079,9 +1085,16 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     HIPE(e, hipEventRecord(e->ev[5], e->stream));
     HIPE(e, slv.backsolve_aug(e->d_G, vs, nrhs));           // G <- L^-T (L^-1 Y)   (row 0: y~, rows 1..d: G^)
     HIPE(e, hipEventRecord(e->ev[6], e->stream));
-    std::vector<double> X((size_t)nrhs * vs);
+    X.assign((size_t)nrhs * vs, 0.0);
     HIPE(e, hipMemcpyAsync(X.data(), e->d_G, X.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-    const int info = slv.fetch_info();
+    info = slv.fetch_info();
+    if (info == -9 && attempt < 2) {
+        ++e->flow_retries;
+        fprintf(stderr, "jaicov: factorisation abandoned on the device (a wait ran into its time limit); repeating it (%d)\n", attempt + 1);
+        continue;
+    }
+    break;
+    }
     if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation did not complete on the device (code " + std::to_string(info) + ")");
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "normal-equation matrix is singular / not positive definite at pivot " + std::to_string(info));
     // ---- rank-d border algebra on the host ---------------------------------------------------------------------
