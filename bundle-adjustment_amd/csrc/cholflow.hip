@@ -1,4 +1,5 @@
-// Dataflow Cholesky: the whole factorisation L L' = M (plus the right-hand-side rows below M) as TWO concurrent launches.
+// Dataflow Cholesky: the whole factorisation L L' = M (plus the right-hand-side rows below M) as TWO concurrent launches
+// (from 24 block columns on; dense.hip's stream-scheduled potrf_streams() below that).
 // Replaces the arithmetic of dpptrf / the factorisation half of dspsv (MathExtension.java:248,348) like dense.hip's
 // stream-scheduled potrf(), with the dependencies carried by flags in memory instead of streams, events and launches.
 //
@@ -10,24 +11,33 @@
 //                       the pipeline fill are paid once per tile, not once per 512 columns), then the tile is finished:
 //                       a diagonal tile goes to the diagonal kernel, an off-diagonal one is multiplied by inv(L_jj)'
 //                       and published.
-//   potrf_diag_chain_kernel   ONE workgroup on a reserved CU (it needs 150 KB of LDS): for c = 0, 1, ...: waits for the
+//   potrf_chain_kernel  the default companion (chain form): two workgroups on reserved CUs (150 KB of LDS each).  Workgroup 0
+//                       keeps the critical chain potrf(c) -> L[c+1][c] -> diagonal tile (c+1, c+1) -> potrf(c+1) inside one
+//                       CU (LDS + accumulators, no trip through memory and flags between the links); workgroup 1 inverts
+//                       the factors.  The tile kernel hands the two tiles over as partial visits (`applied` flags).
+//   potrf_diag_chain_kernel   the first companion (JAICOV_FLOW_CHAIN=0): ONE workgroup: for c = 0, 1, ...: waits for the
 //                       updated diagonal tile c, factors and inverts it (potrf_diag.h), publishes L_cc and inv(L_cc).
+//   chol_tile_kernel<.., true>   the one-kernel form for hosts on which two kernels cannot run side by side.
 //
 // Order and progress.  Tickets are handed out in the order of the host-built task list, which is a topological order of
-// the dependencies (column-major: a task only ever waits for tiles of earlier tickets, and for the diagonal kernel, which
-// only waits for a task).  A ticket is drawn by a RUNNING workgroup, so every ticket below a waiting workgroup's own is
+// the dependencies (column-major: a task only ever waits for tiles of earlier tickets, and for the companion kernel, which
+// only waits for tasks).  A ticket is drawn by a RUNNING workgroup, so every ticket below a waiting workgroup's own is
 // held by a workgroup that is running or has finished: no deadlock whatever the residency, and no assumption about the
-// dispatch order.  The diagonal kernel runs on its own CU-masked stream, so it is resident whatever the tile kernel fills.
-// Every spin is bounded (wall clock): a stall sets the abort word, every waiter leaves, the host reports an error.
+// dispatch order (tests/test_flow_schedule.py replays every form's list against a model of the companion).  The companion
+// runs on its own CU-masked stream and the host launches the tile kernel only once it is resident.
+// Every wait is bounded (wall clock): a stall sets the abort word, every waiter leaves, the host repeats the factorisation
+// or reports an error (engine.hip, solve).
 //
 // Visibility (MI355X_MICROARCH.md, inter-workgroup visibility; the per-XCD L2s are not coherent, a CU's L1 is never
 // refreshed by other CUs' stores).  Producer: every byte that another workgroup will read is stored write-through
-// (`sc1`, agent-scope relaxed atomic stores: the line leaves the storing XCD's L2), every storing wave drains
-// (`s_waitcnt vmcnt(0)`), the workgroup's barrier, then one lane stores the flag (`sc1`).  The diagonal kernel stores
-// plainly and publishes behind an agent-scope release.  Consumer: one lane polls with relaxed `sc1` loads, then ONE
-// agent-scope acquire (invalidates this CU's L1) + `s_waitcnt vmcnt(0)` + barrier, then plain loads.  No stale line can
-// sit in a reader's L2: a tile is read either by the one workgroup that also writes it next (its own XCD's L2, and the
-// write drops the line), or only after it has become final, after which it is never written again.
+// (`sc1`: 8-byte agent-scope atomic stores, or 16 bytes by inline asm -- store_wt2, with the wait states the compiler cannot
+// know about), every storing wave drains (`s_waitcnt vmcnt(0)`), the workgroup's barrier, then one lane stores the flag
+// (system scope).  Consumer: one lane / one wave polls with relaxed `sc1` loads -- in the slow branch also at system scope and
+// by a read-modify-write, see flow_spin --, then ONE agent-scope acquire (invalidates this CU's L1) + `s_waitcnt vmcnt(0)` +
+// barrier, then plain loads.  No stale line can sit in a reader's L2: a tile is read before it is final only by the
+// workgroup that writes it next, write-through stores drop the line from the writer's L2, and a final tile is never written
+// again.  DESIGN.md section 4 records what was nevertheless observed (polls missing flags that were set, about once in
+// 300-1000 factorisations before the flags went to system scope).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -960,8 +970,6 @@ hipError_t DenseSolver::flow_init() {
     flow_alive[0] = flow_alive[1] = flow_alive[2] = flow_alive[3] = 0;
     HIPCHK(hipEventCreateWithFlags(&flow_e0, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&flow_e1, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&flow_e2, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&flow_e3, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&flow_t0));
     HIPCHK(hipEventCreate(&flow_t1));
     flow_ready = true;
@@ -977,10 +985,10 @@ void DenseSolver::flow_release() {
     flow_diag_scratch = nullptr;
     if (flow_alive) hipHostFree(flow_alive);
     flow_alive = nullptr;
-    for (hipEvent_t e : {flow_e0, flow_e1, flow_e2, flow_e3, flow_t0, flow_t1})
+    for (hipEvent_t e : {flow_e0, flow_e1, flow_t0, flow_t1})
         if (e) hipEventDestroy(e);
     flow_task_list = nullptr; flow_flags = nullptr; flow_scratch = nullptr; flow_trace = nullptr;
-    flow_e0 = flow_e1 = flow_e2 = flow_e3 = flow_t0 = flow_t1 = nullptr;
+    flow_e0 = flow_e1 = flow_t0 = flow_t1 = nullptr;
     flow_ready = false;
 }
 

@@ -28,7 +28,6 @@ struct DenseSolver {
     hipStream_t pstream = nullptr;   // panel GEMMs (high priority)
     hipStream_t ustream = nullptr;   // trailing updates: all CUs except the reserved ones (CU mask)
     hipStream_t dstream = nullptr;   // diagonal-block kernel: the reserved CUs
-    hipStream_t ustream2 = nullptr;  // second stream with the update mask (dataflow factorisation: second half of the tile kernel's workgroups)
     std::vector<hipEvent_t> sync_ev;
     size_t ev_used = 0;
     hipEvent_t next_event();
@@ -66,7 +65,7 @@ struct DenseSolver {
     bool flow_kernels_overlap();         // probed once per process
     int *flow_alive = nullptr;           // host-visible: sequence number of the last diagonal kernel that has started
     int flow_seq = 0;
-    hipEvent_t flow_e0 = nullptr, flow_e1 = nullptr, flow_e2 = nullptr, flow_e3 = nullptr, flow_t0 = nullptr, flow_t1 = nullptr;
+    hipEvent_t flow_e0 = nullptr, flow_e1 = nullptr, flow_t0 = nullptr, flow_t1 = nullptr;
     // source of the NEXT potrf(): M = V N V + Bh' Bh read straight from N by the tile kernel (no scaled copy into L first)
     const double *flow_src = nullptr, *flow_V = nullptr, *flow_Bh = nullptr;
     long flow_src_ld = 0;

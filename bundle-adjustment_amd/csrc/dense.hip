@@ -282,8 +282,7 @@ void DenseSolver::release() {
     if (pstream) hipStreamDestroy(pstream);
     if (ustream) hipStreamDestroy(ustream);
     if (dstream) hipStreamDestroy(dstream);
-    if (ustream2) hipStreamDestroy(ustream2);
-    pstream = ustream = dstream = ustream2 = nullptr;
+    pstream = ustream = dstream = nullptr;
     L = invd = W = Q = nullptr;
     d_info = nullptr;
     owns = false;
