@@ -202,6 +202,102 @@ __global__ __launch_bounds__(T_NT) void blk_T_kernel(DevProblem p, const int32_t
     }
 }
 
+// The same product on the matrix cores (default; JAICOV_T_VECTOR=1 selects the kernel above).  T = Dinv [A_c | w] is a skinny
+// GEMM (m x m times m x 30): as vector FMAs it needs 30 v_fma_f64 per 8 bytes of Dinv and ran at 36 % of the fp64 vector rate
+// (LDS broadcast reads and FMA issue beside the streaming loads: 1.07 ms for the 4 GB at config 4); one v_mfma_f64_16x16x4
+// does the work of 16 of those instructions.  A workgroup = 256 rows of one image, a wave 64 rows x 32 columns (4 x 2 MFMA
+// tiles).  The A operand is read through the symmetry of Dinv as its transpose -- lane (l15, l4) of row tile t takes
+// Dinv[k + l4][i0 + 16 t + l15]: 16 consecutive doubles per k, whole lines -- 32 k ahead of the MFMAs that use it; the B
+// operand [A_c | w] of 64 k comes from LDS.
+constexpr int TM_LD = 40;      // LDS row stride of the staged [A_c | w] (32 columns + padding)
+__global__ __launch_bounds__(256, 2) void blk_T_mfma_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                            const double *__restrict__ rowsA, const double *__restrict__ rowsW,
+                                                            double *__restrict__ T) {
+    __shared__ double Ac[64 * TM_LD];
+    const int g = blk_list[blockIdx.y];
+    const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
+    if ((int)blockIdx.x * 256 >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+    const long S = p.n_ip;
+    const int img = p.ip_image[ipb], cam = p.image_camera[img];
+    const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
+    const double *P = p.blk_w + p.blk_w_offset[g];
+    const int i0 = blockIdx.x * 256 + 64 * wave;
+    d4_t acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int u = 0; u < 2; u++) acc[t][u] = (d4_t){0.0, 0.0, 0.0, 0.0};
+    // the lane's four columns of Dinv (clamped: rows beyond m are not stored)
+    const double *pc[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) pc[t] = P + min(i0 + 16 * t + l15, m - 1);
+    double cur[8][4], nxt[8][4];
+    auto fetch = [&](double (&v)[8][4], int kbase) __attribute__((always_inline)) {     // 32 k from kbase on (clamped rows: their B rows are zero)
+#pragma unroll
+        for (int ks = 0; ks < 8; ks++) {
+            const long row = (long)min(kbase + 4 * ks + l4, m - 1) * m;
+#pragma unroll
+            for (int t = 0; t < 4; t++) v[ks][t] = pc[t][row];
+        }
+    };
+    // [A_c | w] of 64 rows k: 8 values per thread, fetched one block ahead as well (zeros beyond m and beyond kc)
+    double sv[8];
+    auto stage_fetch = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int idx = tid + 256 * j, c = idx >> 6, kk = idx & 63;
+            const int k = kb + kk, o = k >> 1, rr = k & 1;
+            double v = 0.0;
+            if (k < m) {
+                if (c < kc) v = rowsA[(long)(2 * shared_local(c) + rr) * S + ipb + o];
+                else if (c == kc) v = rowsW[(long)rr * S + ipb + o];
+            }
+            sv[j] = v;
+        }
+    };
+    stage_fetch(0);
+    fetch(cur, 0);
+    for (int k0 = 0; k0 < m; k0 += 64) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int idx = tid + 256 * j;
+            Ac[(idx & 63) * TM_LD + (idx >> 6)] = sv[j];
+        }
+        __syncthreads();
+        stage_fetch(k0 + 64);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            fetch(nxt, k0 + 32 * half + 32);                   // past the end: clamped reads of the last row, never used
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++) {
+                const double *br = Ac + (32 * half + 4 * ks + l4) * TM_LD + l15;
+                const double b0 = br[0], b1 = br[16];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[ks][t], b0, acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[ks][t], b1, acc[t][1], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ks++)
+#pragma unroll
+                for (int t = 0; t < 4; t++) cur[ks][t] = nxt[ks][t];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = i0 + 16 * t + l4 + 4 * r;
+            if (row >= m) continue;
+            double *out = T + ((long)2 * ipb + row) * KC_LD;
+            out[l15] = acc[t][0][r];
+            if (16 + l15 < KC_LD) out[16 + l15] = acc[t][1][r];
+        }
+}
+
 // B2: shared block S_cc = A_c' T_c, n_c = A_c' T_w.  Two launches, and no atomics: every image block deals its rows to
 // gridDim.y workgroups (one workgroup per image left 500 serial iterations on a quarter-filled chip) which store their partial
 // sums; blk_cc_reduce_kernel then adds them up in a FIXED order (block list order, then part order), so that the camera block of
@@ -753,7 +849,9 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
                                   double *cc_partial) {
     if (n_list <= 0) return hipSuccess;
     const int schur = sb.active ? 1 : 0;
-    hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
+    static const bool t_vector = getenv("JAICOV_T_VECTOR") != nullptr;
+    if (t_vector) hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
+    else hipLaunchKernelGGL(blk_T_mfma_kernel, dim3((max_m + 255) / 256, n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T);
     DevProblem q = p;
     double s2 = sigma2;
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
