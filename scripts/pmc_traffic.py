@@ -8,11 +8,11 @@ Usage: python scripts/pmc_traffic.py <fetch_dir> <write_dir> [tag]"""
 import csv, glob, json, os, sys, time
 
 DOMINANT = "chol_tile_kernel"
-ASSEMBLY = ["rows_kernel", "blk_T_kernel", "blk_elim_kernel", "blk_tfix_kernel", "blk_cc_kernel", "blk_pc_gather_kernel",
+ASSEMBLY = ["rows_kernel", "blk_T_mfma_kernel", "blk_T_kernel", "blk_elim_kernel", "blk_tfix_kernel", "blk_cc_kernel", "blk_pc_gather_kernel",
             "blk_pp_gather_kernel", "zero_lower_kernel", "direct_kernel"]
 # algorithmic bytes per launch at config 4 (500 images, m = 1000 rows per image, reduced order 15014): DESIGN.md section 4
 M2 = 500 * 1000.0 ** 2
-ALGO = {"blk_T_kernel": 8 * M2, "blk_pp_gather_kernel": 4 * M2 + 4 * 15014.0 ** 2, "rows_kernel": 250000 * 460.0,
+ALGO = {"blk_T_kernel": 8 * M2, "blk_T_mfma_kernel": 8 * M2, "blk_pp_gather_kernel": 4 * M2 + 4 * 15014.0 ** 2, "rows_kernel": 250000 * 460.0,
         "zero_lower_kernel": 0.0}
 
 
