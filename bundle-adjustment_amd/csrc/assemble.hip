@@ -846,7 +846,7 @@ hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb,
-                                  double *cc_partial) {
+                                  double *cc_partial, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (n_list <= 0) return hipSuccess;
     const int schur = sb.active ? 1 : 0;
     static const bool t_vector = getenv("JAICOV_T_VECTOR") != nullptr;
@@ -862,17 +862,33 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         if (sb.materialise) q.blk_w = sb.Pp;
         s2 = 1.0;
     }
+    // The camera-side blocks (camera x camera, point x camera, their parts of n) and the point x point gather write disjoint
+    // parts of N (the gather owns the point rows from the first point column on and does not touch n) and read the same
+    // finished T / U: with a side stream the three small kernels -- 0.4 ms of mostly latency -- run beside the gather, which
+    // is latency-bound itself, instead of in front of it.  Their own order stays (the sums into n keep their order).
     static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::min(16, std::max(1, atoi(getenv("JAICOV_CC_PARTS")))) : 8;
-    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, s, p, blk_list, rowsA, T, s2, cc_partial, schur);
-    hipLaunchKernelGGL(blk_cc_reduce_kernel, dim3(CC_ENT, p.n_cameras), dim3(256), 0, s, p, blk_list, n_list, cc_parts, cc_partial, N, n, schur);
+    static const bool no_fork = getenv("JAICOV_NO_ASSEMBLY_FORK") != nullptr;
+    const bool fork = side && ev_fork && ev_join && pp.pt_ip_begin && !no_fork;
+    hipStream_t cs = fork ? side : s;
+    if (fork) {
+        hipError_t he = hipEventRecord(ev_fork, s);
+        if (he == hipSuccess) he = hipStreamWaitEvent(side, ev_fork, 0);
+        if (he != hipSuccess) return he;
+    }
+    hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, cs, p, blk_list, rowsA, T, s2, cc_partial, schur);
+    hipLaunchKernelGGL(blk_cc_reduce_kernel, dim3(CC_ENT, p.n_cameras), dim3(256), 0, cs, p, blk_list, n_list, cc_parts, cc_partial, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
     static const bool pc_atomic = getenv("JAICOV_PC_ATOMIC") != nullptr;
     if (pp.pt_ip_begin && !pc_atomic) {
         const long totp = (long)p.n_points * KC_LD;
-        hipLaunchKernelGGL(blk_pc_gather_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0, s, p, pp, rowsA, T, s2, N, n, schur);
+        hipLaunchKernelGGL(blk_pc_gather_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0, cs, p, pp, rowsA, T, s2, N, n, schur);
     } else
-        hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, (const int32_t *)nullptr,
+        hipLaunchKernelGGL(blk_pc_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, cs, p, (const int32_t *)nullptr,
                            ip_list, n_ip_list, rowsA, T, s2, N, n, schur);
+    if (fork) {
+        hipError_t he = hipEventRecord(ev_join, side);
+        if (he != hipSuccess) return he;
+    }
     if (pp.pt_ip_begin) {
         const dim3 gg(p.n_points, pp.n_chunks), gb(PP_NT);
         const bool det = pp.range_sub != nullptr;
@@ -887,6 +903,10 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         if (schur && !sb.materialise) return hipErrorInvalidValue;   // the per-pair atomic kernel reads a materialised P'
         const int mp = max_m / 2;
         hipLaunchKernelGGL(blk_pp_kernel, dim3((mp + 63) / 64, mp, n_list), dim3(192), 0, s, q, blk_list, rowsA, s2, N);
+    }
+    if (fork) {
+        hipError_t he = hipStreamWaitEvent(s, ev_join, 0);
+        if (he != hipSuccess) return he;
     }
     return hipGetLastError();
 }

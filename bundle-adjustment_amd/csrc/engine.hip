@@ -24,7 +24,7 @@ hipError_t launch_assemble_small(hipStream_t, const DevProblem &, const int32_t 
                                  const double *, double, double *, double *);
 hipError_t launch_assemble_blocks(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
                                   const double *, const double *, double *, double, double *, double *, const PPGather &,
-                                  const SchurBufs &, double *);
+                                  const SchurBufs &, double *, hipStream_t, hipEvent_t, hipEvent_t);
 hipError_t launch_schur_backsub(hipStream_t, const DevProblem &, const int32_t *, int, const double *, const double *,
                                 const double *, double *);
 hipError_t launch_shared_groups(hipStream_t, const DevProblem &, const double *, double, double *, double *,
@@ -163,6 +163,7 @@ struct jaicov_engine {
     std::string err = "";
     int device = 0;
     int flow_retries = 0;      // dataflow factorisations that were abandoned and repeated (solve)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // assembly: camera-side kernels on a side stream (assemble.hip)
     hipStream_t stream = nullptr;
     DevProblem p{};
     std::vector<void *> allocs;
@@ -295,6 +296,8 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     for (void *ptr : e->allocs) hipFree(ptr);
     for (auto &evt : e->ev)
         if (evt) hipEventDestroy(evt);
+    if (e->ev_fork) hipEventDestroy(e->ev_fork);
+    if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_first) hipEventDestroy(e->ev_first);
     if (e->ev_all) hipEventDestroy(e->ev_all);
     if (e->stream) hipStreamDestroy(e->stream);
@@ -316,6 +319,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     HIPE(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto &evt : e->ev) HIPE(e, hipEventCreate(&evt));
     HIPE(e, hipEventCreateWithFlags(&e->ev_first, hipEventDisableTiming));
+    HIPE(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIPE(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIPE(e, hipEventCreateWithFlags(&e->ev_all, hipEventDisableTiming));
 
     const int U = D->n_unknowns, d = D->rank_defect;
@@ -815,7 +820,8 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
         PPGather ppg = e->pp;
         ppg.plain = plain ? 1 : 0;
         HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
-                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, ppg, sb, e->d_cc_partial));
+                                       e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, ppg, sb, e->d_cc_partial,
+                                       e->solver.pstream, e->ev_fork, e->ev_join));   // side stream: the solver's (idle during the assembly)
     }
     if (plain)   // the images outside the dense blocks come after the stores
         HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
