@@ -849,7 +849,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
                                   double *cc_partial, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (n_list <= 0) return hipSuccess;
     const int schur = sb.active ? 1 : 0;
-    static const bool t_vector = getenv("JAICOV_T_VECTOR") != nullptr;
+    const bool t_vector = getenv("JAICOV_T_VECTOR") != nullptr;
     if (t_vector) hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
     else hipLaunchKernelGGL(blk_T_mfma_kernel, dim3((max_m + 255) / 256, n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T);
     DevProblem q = p;
@@ -867,7 +867,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     // finished T / U: with a side stream the three small kernels -- 0.4 ms of mostly latency -- run beside the gather, which
     // is latency-bound itself, instead of in front of it.  Their own order stays (the sums into n keep their order).
     static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::min(16, std::max(1, atoi(getenv("JAICOV_CC_PARTS")))) : 8;
-    static const bool no_fork = getenv("JAICOV_NO_ASSEMBLY_FORK") != nullptr;
+    const bool no_fork = getenv("JAICOV_NO_ASSEMBLY_FORK") != nullptr;
     const bool fork = side && ev_fork && ev_join && pp.pt_ip_begin && !no_fork;
     hipStream_t cs = fork ? side : s;
     if (fork) {

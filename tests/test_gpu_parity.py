@@ -143,6 +143,29 @@ def test_normal_equations_match_oracle(oracle_mod, name):
         eng.close()
 
 
+@pytest.mark.parametrize("switch", ["JAICOV_T_VECTOR", "JAICOV_NO_ASSEMBLY_FORK", "JAICOV_PP_MATERIALISE"])
+def test_assembly_switches_give_the_same_system(switch, monkeypatch):
+    """The alternative forms of the dense-block assembly kept behind switches (vector form of T = Dinv [A_c | w], camera-side
+    kernels in front of the gather instead of beside it, P' written out) assemble the same EO-reduced system as the default
+    and the same step (the default is held to the oracle by the tests around this one)."""
+    fp = scene.make_scene(12, 150, 90, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    s2 = fp.sigma2apriori
+    res = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv(switch, "1")
+        eng = engine.Engine(fp)
+        eng.set_parameters(fp.values)
+        eng.build(s2, 0.5)
+        N, n = eng.get_normal()
+        res.append((N.copy(), n.copy(), eng.solve(False)))
+        eng.close()
+    (N0, n0, dx0), (N1, n1, dx1) = res
+    np.testing.assert_allclose(N1, N0, rtol=0, atol=1e-12 * np.abs(N0).max())
+    np.testing.assert_allclose(n1, n0, rtol=0, atol=1e-12 * np.abs(n0).max())
+    np.testing.assert_allclose(dx1, dx0, rtol=0, atol=1e-10 * np.abs(dx0).max())
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
 @pytest.mark.parametrize("invert", [False, True])
 def test_solve_matches_oracle(oracle_mod, name, invert):
