@@ -954,7 +954,17 @@ hipError_t DenseSolver::flow_init() {
     HIPCHK(hipMemcpy(flow_task_list, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
     flow_fs = nb;
     flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + 2 * nb + 1024;   // ... + one state word per workgroup
-    HIPCHK(hipMalloc(&flow_flags, flow_words * sizeof(int)));
+    // The flags live in FINE-GRAINED device memory (coherent across the XCDs while a kernel runs): in ordinary (coarse-grained)
+    // memory polls of every flavour -- sc1, system scope, read-modify-write, with an acquire in between -- were seen to miss
+    // flags that memory held as set, about once in 1 000-2 400 factorisations ("Visibility").
+    // JAICOV_FLOW_COARSE_FLAGS=1: the old allocation.
+    flow_flags = nullptr;
+    if (!getenv("JAICOV_FLOW_COARSE_FLAGS") &&
+        hipExtMallocWithFlags((void **)&flow_flags, flow_words * sizeof(int), hipDeviceMallocFinegrained) != hipSuccess) {
+        flow_flags = nullptr;
+        (void)hipGetLastError();
+    }
+    if (!flow_flags) HIPCHK(hipMalloc(&flow_flags, flow_words * sizeof(int)));
     HIPCHK(hipMemset(flow_flags, 0, flow_words * sizeof(int)));
     int cus = 256;
     hipDeviceProp_t prop;
