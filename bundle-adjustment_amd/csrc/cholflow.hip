@@ -59,7 +59,7 @@ namespace jaicov {
     } while (0)
 
 // control words
-enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CHAIN_AT = 3, FLOW_STALE = 4, FLOW_STALE_CONFIRMED = 5, FLOW_RESCUED = 6, FLOW_CTRL_WORDS = 16 };   // RESCUED: hits of the read-modify-write poll after > 1 ms of waiting   // CHAIN_AT: column << 4 | stage of the chain workgroup
+enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CHAIN_AT = 3, FLOW_STALE = 4, FLOW_STALE_CONFIRMED = 5, FLOW_RESCUED = 6, FLOW_WG_OFF = 7, FLOW_CTRL_WORDS = 16 };   // RESCUED: hits of the read-modify-write poll after > 1 ms of waiting   // CHAIN_AT: column << 4 | stage of the chain workgroup
 constexpr int FLOW_FIN = 1 << 20;        // task.w = k1 | FLOW_FIN: finish the tile after the updates
 constexpr int FLOW_LDS = 144;            // LDS row stride of both operands (gemm_f64.h: == 16 mod 32 doubles)
 constexpr int FLOW_STAGE = GEMM_BK * 2 * FLOW_LDS;
@@ -127,6 +127,15 @@ __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0
 
 #define FLOW_OPAQUE_TID(name) int name = tid; asm volatile("" : "+v"(name))
 
+// The lane whose wait runs out: set the abort word and, if it is the first, copy every workgroup's state word next to it (what the
+// others were doing at THAT moment; flow_report_stall prints it beside what they had reached when the kernel ended).
+__device__ __forceinline__ void flow_give_up(int *ctrl) {
+    if (atomicCAS(ctrl + FLOW_ABORT, 0, 2) == 0) {
+        int *wg = ctrl + ctrl[FLOW_WG_OFF];
+        for (int b = 0; b < 1024; b++) wg[1024 + b] = flow_ld(wg + b);
+    }
+}
+
 // One lane: spin until *flag >= want.  Returns false when the factorisation is abandoned (abort word set / timeout).
 __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, long long timeout, long long *waited) {
     if (flow_ld(flag) >= want) return true;
@@ -146,7 +155,7 @@ __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, 
                     break;
                 }
                 if (flow_ld(ctrl + FLOW_ABORT) != 0) { ok = false; break; }
-                if (wall_clock64() - t0 > timeout) { flow_st(ctrl + FLOW_ABORT, 2); ok = false; break; }
+                if (wall_clock64() - t0 > timeout) { flow_give_up(ctrl); ok = false; break; }
             }
         }
     }
@@ -389,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                                         break;
                                     }
                                     if (flow_ld(g.ctrl + FLOW_ABORT) != 0) break;
-                                    if (wall_clock64() - t0 > g.timeout) { flow_st(g.ctrl + FLOW_ABORT, 2); break; }
+                                    if (wall_clock64() - t0 > g.timeout) { if (lane == 0) flow_give_up(g.ctrl); break; }
                                 }
                             }
                         }
@@ -705,6 +714,10 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
     __shared__ int s_ok;
     const int tid = threadIdx.x;
     if (tid == 0 && g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid == 0) {      // where this workgroup runs (flow_report_stall): HW_ID, XCC_ID
+        flow_st(g.ctrl + 8 + 2 * blockIdx.x, (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
+        flow_st(g.ctrl + 9 + 2 * blockIdx.x, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf));
+    }
     if (blockIdx.x == 1) {
         // ---- the inverses ----------------------------------------------------------------------------------------------
         for (int c = 0; c < g.nb; c++) {
@@ -953,7 +966,7 @@ hipError_t DenseSolver::flow_init() {
     HIPCHK(hipMalloc(&flow_task_list, tasks.size() * sizeof(int4)));
     HIPCHK(hipMemcpy(flow_task_list, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
     flow_fs = nb;
-    flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + 2 * nb + 1024;   // ... + one state word per workgroup
+    flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + 2 * nb + 2048;   // ... + one state word per workgroup, and room for their copy at the moment a wait runs out
     // The flags live in FINE-GRAINED device memory (coherent across the XCDs while a kernel runs): in ordinary (coarse-grained)
     // memory polls of every flavour -- sc1, system scope, read-modify-write, with an acquire in between -- were seen to miss
     // flags that memory held as set, about once in 1 000-2 400 factorisations ("Visibility").
@@ -983,6 +996,7 @@ hipError_t DenseSolver::flow_init() {
     HIPCHK(hipEventCreate(&flow_t0));
     HIPCHK(hipEventCreate(&flow_t1));
     flow_ready = true;
+    if (getenv("JAICOV_FLOW_TRACE_ON")) HIPCHK(flow_enable_trace(true));     // per-task timestamps, read by flow_report_stall
     return hipSuccess;
 }
 
@@ -1016,9 +1030,11 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.info = d_info;
     g.scratch = flow_scratch;
     g.zeros = flow_scratch + (size_t)flow_grid * 16384;
-    // time limit of a single wait, 100 MHz ticks: 0.5 s (a whole factorisation takes 0.7-40 ms; the longest ordinary wait ~2 ms)
+    // time limit of a single wait, 100 MHz ticks: 0.25 s + 10 x the time the whole factorisation should take at 20 TFLOP/s
+    // (order 15 104: 0.25 + 0.57 s... the longest ordinary wait there is ~2 ms)
+    const double expect_ms = (double)nfact * nfact * nfact / 3.0 / 20e9;
     g.timeout = getenv("JAICOV_FLOW_TIMEOUT_S") ? 100000000LL * atoi(getenv("JAICOV_FLOW_TIMEOUT_S"))
-                                                 : 100000LL * (getenv("JAICOV_FLOW_TIMEOUT_MS") ? atoi(getenv("JAICOV_FLOW_TIMEOUT_MS")) : 500);
+                                                 : 100000LL * (getenv("JAICOV_FLOW_TIMEOUT_MS") ? atoi(getenv("JAICOV_FLOW_TIMEOUT_MS")) : (int)(250 + 10 * expect_ms));
     g.src = flow_src; g.src_ld = flow_src_ld; g.V = flow_V; g.Bh = flow_Bh; g.d = flow_d; g.U = flow_U; g.bstride = flow_bstride;
     flow_src = nullptr;      // one factorisation only
     g.trace = flow_trace;
@@ -1031,6 +1047,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.alive = flow_alive;
     g.seq = ++flow_seq;
     HIPCHK(hipMemsetAsync(flow_flags, 0, flow_words * sizeof(int), stream));
+    flow_wg_off = (int)(g.wgstate - g.ctrl);
+    HIPCHK(hipMemcpyAsync(flow_flags + FLOW_WG_OFF, &flow_wg_off, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
     static const int pf = getenv("JAICOV_FLOW_PF") ? atoi(getenv("JAICOV_FLOW_PF")) : 1;   // measured equal (22.7-23.0 ms at order 15104): one step of lead covers the latency
     if (flow_one_kernel) {
@@ -1109,6 +1127,11 @@ void DenseSolver::flow_report_stall() {
                     applied[(size_t)(c + 1) * nb + c] - 1, applied[(size_t)(c + 1) * nb + c + 1] - 1, c);
     }
     fprintf(stderr, "\n");
+    for (int b = 0; b < 3; b++) {
+        const unsigned hw = (unsigned)f[8 + 2 * b];
+        if (flow_chain && (b < 2 || flow_second))
+            fprintf(stderr, "jaicov:   chain workgroup %d runs on [xcc %d se %u sh %u cu %u]\n", b, f[9 + 2 * b], (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf);
+    }
     // the oldest tickets still in flight, and what their workgroups were doing (1 drawn, 2 waiting for an earlier visit / the
     // inverse, 3 polling operand flags at block column k, 4 products, 5 / 6 storing after phase 0 / 1, 7 finished, 8 gave up)
     const int *wg = factored + nb;
@@ -1116,11 +1139,37 @@ void DenseSolver::flow_report_stall() {
     for (int b = 0; b < std::min(flow_grid, 1024); b++)
         if (wg[b] != 0 && (wg[b] & 15) != 7) open.push_back({wg[b] >> 12, b});
     std::sort(open.begin(), open.end());
+    std::vector<long long> tr;
+    if (flow_trace) {
+        tr.resize((size_t)flow_tasks * 8);
+        if (hipMemcpy(tr.data(), flow_trace, tr.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) tr.clear();
+    }
+    long long t_last = 0;
+    for (size_t q = 0; q + 7 < tr.size(); q += 8) t_last = std::max(t_last, tr[q + 3]);
+    auto ticket_of = [&](int i, int j) {
+        for (int t = 0; t < flow_tasks; t++)
+            if (flow_task_host[t].x == i && flow_task_host[t].y == j) return t;
+        return -1;
+    };
     for (size_t q = 0; q < open.size() && q < 6; q++) {
         const int w = wg[open[q].second], t = w >> 12;
         const int4 tk = flow_task_host.empty() ? make_int4(-1, -1, 0, 0) : flow_task_host[t];
         fprintf(stderr, "jaicov:   workgroup %d: ticket %d = tile (%d, %d) to block column %d%s, stage %d at block column %d\n", open[q].second, t, tk.x,
                 tk.y, tk.w & (FLOW_FIN - 1), (tk.w & FLOW_FIN) ? " + finish" : "", w & 15, (w >> 4) & 255);
+        // with JAICOV_FLOW_TRACE_ON: when were the two operand tiles it was waiting for finished (ms before the last recorded event)?
+        const int kk = (w >> 4) & 255;
+        if (!tr.empty() && (w & 15) == 8 && kk < tk.y)
+            for (int side = 0; side < 2; side++) {
+                const int oi = side == 0 ? tk.x : tk.y, ot = ticket_of(oi, kk);
+                if (ot < 0) continue;
+                const long long *r = &tr[(size_t)ot * 8];
+                const unsigned hw = (unsigned)(r[7] & 0xffffffff);
+                const int ws = wg[1024 + (int)(r[6] & 0xffff)];
+                fprintf(stderr, "jaicov:     (when the first wait ran out that workgroup was at: ticket %d, block column %d, stage %d)\n", ws >> 12, (ws >> 4) & 255, ws & 15);
+                fprintf(stderr, "jaicov:     operand tile (%d, %d) = ticket %d on workgroup %d [xcc %d se %u sh %u cu %u simd %u wave %u]: started %.3f ms, tile loaded %.3f ms, updates done %.3f ms, finished %.3f ms before the end; it waited %.3f ms\n",
+                        oi, kk, ot, (int)(r[6] & 0xffff), (int)((r[7] >> 32) & 0xf), (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf, (hw >> 4) & 3, hw & 0xf,
+                        (t_last - r[0]) / 1e5, (t_last - r[1]) / 1e5, (t_last - r[2]) / 1e5, r[3] ? (t_last - r[3]) / 1e5 : -1.0, r[4] / 1e5);
+            }
     }
 }
 

@@ -51,6 +51,7 @@ struct DenseSolver {
 
     // dataflow factorisation (cholflow.hip): the whole potrf as two concurrent launches, dependencies as flags in memory
     bool flow_ready = false, flow_timed = false, flow_chain = false, flow_one_kernel = false;
+    int flow_wg_off = 0;                 // offset of the per-workgroup state words in flow_flags (read by the device)
     int flow_second = 0;                 // third chain workgroup (cholflow.hip)
     long long flow_stale_events = 0, flow_stale_confirmed = 0, flow_rescued = 0;   // flags that only the read-modify-write poll saw (fetch_info)
     std::vector<int4> flow_task_host;    // the task list (flow_report_stall)

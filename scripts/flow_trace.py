@@ -108,3 +108,16 @@ if want_trace and nt.value:
             print(f"chain {name}: diag kernel + solve of L[j+1][j] {np.mean((b - a)[sl]):.1f} us, last update + store of (j+1,j+1) {np.mean((c - b)[sl]):.1f} us")
     pro = us[:, 1] - us[:, 0]
     print(f"C-tile load: mean {pro.mean():.1f} us p90 {np.percentile(pro, 90):.1f};  finish (after updates): mean {(us[:, 3] - us[:, 2]).mean():.1f} us")
+    if os.environ.get("FLOW_TRACE_WGS"):
+        blk = (t[:, 6] & 0xffff).astype(int)
+        first = {}
+        for row, b in zip(t, blk):
+            if b not in first or row[0] < first[b][0]:
+                first[b] = (row[0], int(row[7] >> 32) & 0xf, int(row[7]) & 0xffffffff)
+        seen = sorted(first)
+        missing = [b for b in range(512) if b not in first]
+        print("workgroups that never ran a task:", missing)
+        late = sorted(first.items(), key=lambda kv: -kv[1][0])[:12]
+        print("latest first task starts (workgroup, us after the first, xcc, se, cu):", [(b, round((v[0] - t0) / 100.0), v[1], (v[2] >> 13) & 7, (v[2] >> 8) & 0xf) for b, v in late])
+        for x in (0, 1):
+            print(f"xcc {x}: workgroups", sorted(b for b, v in first.items() if v[1] == x))
