@@ -93,6 +93,8 @@ struct FlowArgs {
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
     int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
     int crit_prio;           // s_setprio level of the tasks on the critical chain; 0 = none
+    int keep;                // chain form: blocks >= keep on an XCD that hosts a chain workgroup leave at once (0: none do)
+    int second_wg;           // chain form: there is a third chain workgroup
     int second_update;       // chain form: workgroup 2 also subtracts its tile from tile (c+2, c+1)
     int inv_wt;              // chain form: the inverses leave write-through (1) or plainly behind a release (0)
     int crit_span;           // ... which are the tiles (i, j) with i <= j + crit_span
@@ -274,6 +276,16 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
 #undef FLOW_MFMA
     };
 
+    // The workgroups dispatched last on an XCD that hosts a chain workgroup take no tickets.  Those XCDs hold fewer tile
+    // workgroups than the others (a CU is taken, and the dispatcher stops at the first workgroup that does not fit), so the last
+    // ones of the grid stay queued there for the whole run -- and about once in 2 000-3 600 factorisations one of the last
+    // RESIDENT ones (always block 448, 449, 456 or 464 of 512) was seen to stand still inside the product loop, with its flags
+    // ready, until the time limit emptied the chip ("Visibility").  Leaving early, they let the queued
+    // ones through (which leave too): nothing is left queued behind a full shader engine while the factorisation runs.
+    if (!INLINE_DIAG && g.keep > 0 && (int)blockIdx.x >= g.keep) {
+        const int xcc = 1 + (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
+        if (xcc == flow_ld(g.ctrl + 9) || xcc == flow_ld(g.ctrl + 11) || (g.second_wg && xcc == flow_ld(g.ctrl + 13))) return;
+    }
     for (;;) {
         if (tid == 0) s_msg[0] = atomicAdd(g.ctrl + FLOW_TICKET, 1);
         __syncthreads();
@@ -713,10 +725,12 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
     __shared__ double Wd[8 * 16 * WDP];
     __shared__ int s_ok;
     const int tid = threadIdx.x;
-    if (tid == 0 && g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (tid == 0) {      // where this workgroup runs (flow_report_stall): HW_ID, XCC_ID
+    if (tid == 0) {      // where this workgroup runs: HW_ID, XCC_ID + 1 (the tile kernel and flow_report_stall read them) ...
         flow_st(g.ctrl + 8 + 2 * blockIdx.x, (int)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));
-        flow_st(g.ctrl + 9 + 2 * blockIdx.x, (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf));
+        flow_st(g.ctrl + 9 + 2 * blockIdx.x, 1 + (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf));
+        drain_stores();
+        // ... then: resident, the tile kernel may come
+        if (g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (blockIdx.x == 1) {
         // ---- the inverses ----------------------------------------------------------------------------------------------
@@ -1042,6 +1056,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.fake_a = getenv("JAICOV_FLOW_FAKE_A") ? atoi(getenv("JAICOV_FLOW_FAKE_A")) : 0;
     g.crit_prio = getenv("JAICOV_FLOW_PRIO") ? atoi(getenv("JAICOV_FLOW_PRIO")) : 1;
     g.second_update = flow_second >= 2 ? 1 : 0;
+    g.second_wg = flow_second ? 1 : 0;
+    g.keep = flow_chain && !getenv("JAICOV_FLOW_KEEP_ALL") ? 8 * (flow_grid / 8 - 8) : 0;
     g.inv_wt = getenv("JAICOV_FLOW_INV_WT") ? atoi(getenv("JAICOV_FLOW_INV_WT")) : 1;
     g.crit_span = getenv("JAICOV_FLOW_PRIO_SPAN") ? atoi(getenv("JAICOV_FLOW_PRIO_SPAN")) : (flow_chain ? 2 : 1);
     g.alive = flow_alive;
@@ -1130,7 +1146,7 @@ void DenseSolver::flow_report_stall() {
     for (int b = 0; b < 3; b++) {
         const unsigned hw = (unsigned)f[8 + 2 * b];
         if (flow_chain && (b < 2 || flow_second))
-            fprintf(stderr, "jaicov:   chain workgroup %d runs on [xcc %d se %u sh %u cu %u]\n", b, f[9 + 2 * b], (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf);
+            fprintf(stderr, "jaicov:   chain workgroup %d runs on [xcc %d se %u sh %u cu %u]\n", b, f[9 + 2 * b] - 1, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf);
     }
     // the oldest tickets still in flight, and what their workgroups were doing (1 drawn, 2 waiting for an earlier visit / the
     // inverse, 3 polling operand flags at block column k, 4 products, 5 / 6 storing after phase 0 / 1, 7 finished, 8 gave up)
