@@ -36,8 +36,9 @@
 // by a read-modify-write, see flow_spin --, then ONE agent-scope acquire (invalidates this CU's L1) + `s_waitcnt vmcnt(0)` +
 // barrier, then plain loads.  No stale line can sit in a reader's L2: a tile is read before it is final only by the
 // workgroup that writes it next, write-through stores drop the line from the writer's L2, and a final tile is never written
-// again.  DESIGN.md section 4 records what was nevertheless observed (polls missing flags that were set, about once in
-// 300-1000 factorisations before the flags went to system scope).
+// again.  DESIGN.md section 4 ("Visibility") records the rare stalls that were observed and what they turned out to be (not
+// visibility: tile workgroups dispatched last on the XCDs of the chain workgroups standing still inside the product loop;
+// they take no tickets any more, see the top of chol_tile_kernel).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
