@@ -143,3 +143,26 @@ def test_cfg4_cofactor_matrices(cfg4, converged):
     assert (np.abs(Qf_sub - Qr_sub) / np.outer(sd, sd)).max() < 1e-6
     eo = np.arange(e0, fp.n_unknowns, 37, dtype=np.int32)             # the EO part exists only in FULL
     assert np.all(np.diag(eng.get_cofactor_sub(eo)) > 0)
+
+
+def test_cfg4_abandoned_factorisation_is_reported_and_the_engine_stays_usable(cfg4, monkeypatch, capfd):
+    """The dataflow factorisation's waits are bounded (cholflow.hip): with a time limit no factorisation can meet, `solve`
+    repeats it twice (one line on stderr each), then returns JAICOV_ERR_DEVICE -- and the same engine solves the same
+    system once the limit is back to normal."""
+    fp = cfg4
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.build(fp.sigma2apriori, 0.0)
+    ref = eng.solve(False)
+    eng.build(fp.sigma2apriori, 0.0)
+    monkeypatch.setenv("JAICOV_FLOW_TIMEOUT_MS", "0")        # read at every factorisation: any wait beyond ~40 us gives up
+    with pytest.raises(engine.EngineError) as ei:
+        eng.solve(False)
+    assert ei.value.code == -5
+    assert capfd.readouterr().err.count("repeating it") == 2
+    monkeypatch.delenv("JAICOV_FLOW_TIMEOUT_MS")
+    eng.build(fp.sigma2apriori, 0.0)
+    again = eng.solve(False)
+    eng.close()
+    # two assemblies of the same system differ in the last bits (atomics); through cond 1e9 that is 1e-9..1e-8 of a single step
+    np.testing.assert_allclose(again, ref, rtol=0, atol=1e-7 * np.abs(ref).max())
