@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
     // RESIDENT ones (always block 448, 449, 456 or 464 of 512) was seen to stand still inside the product loop, with its flags
     // ready, until the time limit emptied the chip ("Visibility").  Leaving early, they let the queued
     // ones through (which leave too): nothing is left queued behind a full shader engine while the factorisation runs
-    // (12 000 factorisations without a stall since; 5-6 expected at the earlier rate).
+    // (16 000 factorisations without a stall since; 7-8 expected at the earlier rate).
     if (!INLINE_DIAG && g.keep > 0 && (int)blockIdx.x >= g.keep) {
         const int xcc = 1 + (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
         if (xcc == flow_ld(g.ctrl + 9) || xcc == flow_ld(g.ctrl + 11) || (g.second_wg && xcc == flow_ld(g.ctrl + 13))) return;
