@@ -1489,20 +1489,28 @@ extern "C" int jaicov_dense_spd_solve_packed(int32_t n, double *ap, double *b, i
         if (hipMalloc(&d_ap, len * sizeof(double)) != hipSuccess) { status = JAICOV_ERR_OUT_OF_MEMORY; break; }
         hipMalloc(&d_Y, (size_t)DENSE_MAX_RHS * np * sizeof(double));
         hipMemcpyAsync(d_ap, ap, len * sizeof(double), hipMemcpyHostToDevice, s);
-        // identity padding, then unpack the lower triangle
-        hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np, (const int32_t *)nullptr);
-        hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, d_ap, ds.ld, n, ds.L);
-        hipMemsetAsync(ds.rhs_row(0), 0, (size_t)128 * ds.ld * sizeof(double), s);
-        for (int q = 0; q < nrhs; q++) hipMemcpyAsync(ds.rhs_row(q), b + (size_t)q * n, n * sizeof(double), hipMemcpyHostToDevice, s);
-        hipEventRecord(e0, s);
-        if (ds.potrf() != hipSuccess) { status = JAICOV_ERR_DEVICE; break; }
-        if (nrhs > 0) ds.backsolve_aug(d_Y, np, nrhs);
-        if (invert) {
-            ds.trtri();
-            ds.lauum();
+        int info = 0;
+        for (int attempt = 0;; attempt++) {      // an abandoned dataflow factorisation (-9) is repeated: the packed input is still there
+            // identity padding, then unpack the lower triangle
+            hipLaunchKernelGGL(load_disp_kernel, dim3((np + 255) / 256, np), dim3(256), 0, s, (const double *)nullptr, 0, ds.L, ds.ld, np, (const int32_t *)nullptr);
+            hipLaunchKernelGGL(unpack_kernel, dim3((n + 255) / 256, n), dim3(256), 0, s, d_ap, ds.ld, n, ds.L);
+            hipMemsetAsync(ds.rhs_row(0), 0, (size_t)128 * ds.ld * sizeof(double), s);
+            for (int q = 0; q < nrhs; q++) hipMemcpyAsync(ds.rhs_row(q), b + (size_t)q * n, n * sizeof(double), hipMemcpyHostToDevice, s);
+            hipEventRecord(e0, s);
+            if (ds.potrf() != hipSuccess) { info = -1; break; }
+            if (nrhs > 0) ds.backsolve_aug(d_Y, np, nrhs);
+            if (invert) {
+                ds.trtri();
+                ds.lauum();
+            }
+            hipEventRecord(e1, s);
+            info = ds.fetch_info();
+            if (info == -9 && attempt < 2) {
+                fprintf(stderr, "jaicov: factorisation abandoned on the device (a wait ran into its time limit); repeating it (%d)\n", attempt + 1);
+                continue;
+            }
+            break;
         }
-        hipEventRecord(e1, s);
-        const int info = ds.fetch_info();
         if (info < 0) { status = JAICOV_ERR_DEVICE; break; }
         if (info != 0) { status = JAICOV_ERR_SINGULAR; break; }
         for (int q = 0; q < nrhs; q++) hipMemcpyAsync(b + (size_t)q * n, d_Y + (size_t)q * np, n * sizeof(double), hipMemcpyDeviceToHost, s);
