@@ -92,6 +92,7 @@ struct DenseSolver {
     hipError_t potrf(hipEvent_t first_ready = nullptr, hipEvent_t all_ready = nullptr);
     int first_panel_cols() const;
     hipError_t backsolve_aug(double *X, long xs, int nrhs);  // L' X = Z, Z = the rhs rows after potrf(); X rows have stride xs
+    hipError_t solve_rhs(const double *b, double *tmp, double *X);   // X = (L L')^-1 b, one right-hand side (forward + backward chain)
     hipError_t trtri();                                     // W <- L^-1
     hipError_t lauum();                                     // Q <- W' W (lower tiles)
     hipError_t symmetrize(double *M);                       // copy lower -> upper

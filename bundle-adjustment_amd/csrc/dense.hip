@@ -170,6 +170,93 @@ __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__re
     }
 }
 
+// Forward substitution L z = b for ONE right-hand side in one launch: the mirror image of the chain above, for right-hand
+// sides that did not ride through the factorisation (iterative refinement, engine.hip: the residual exists only after the
+// first solution).  Workgroup k owns block ROW k: it streams the blocks L[k][j], j < k (rows of 1 KB: one cache line per
+// 16 lanes), subtracts L[k][j] z_j as soon as the owner of row j has published z_j, then applies the inverse of its
+// diagonal block.  Same flag protocol (Z preset to the all-ones pattern, relaxed agent-scope atomics), same progress
+// argument (a workgroup waits only for workgroups with a smaller index) and the same bounded spin.
+__global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *__restrict__ L, long ld,
+                                                                 const double *__restrict__ invd, const double *__restrict__ B,
+                                                                 double *Z, int nb) {
+    __shared__ __attribute__((aligned(16))) double zj[2][128];      // z_j
+    __shared__ double red[128][65];                                 // per-lane partial sums of the 128 rows
+    __shared__ double part[2][128];
+    __shared__ double bk[128];
+    const int tid = threadIdx.x;
+    const int k = blockIdx.x;
+    const int c2 = tid & 63, qd = tid >> 6;        // block phase: columns 2*c2, 2*c2+1; rows 32*qd .. 32*qd+31
+    const int di = tid & 127, dh = tid >> 7;       // diagonal phase: output row di, columns 64*dh .. 64*dh+63
+    double dinv[64];
+    {
+        const double *w = invd + (long)k * 16384 + (long)di * 128 + 64 * dh;     // row di of inv(L_kk)
+#pragma unroll
+        for (int c = 0; c < 64; c += 2) {
+            const d2_t t = *reinterpret_cast<const d2_t *>(w + c);
+            dinv[c] = t.x; dinv[c + 1] = t.y;
+        }
+        if (tid < 128) bk[tid] = B[k * 128 + tid];
+    }
+    double acc[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) acc[r] = 0.0;
+    d2_t blk[32], nblk[32];
+    if (k > 0) {
+        const double *lp = L + (long)(k * 128 + 32 * qd) * ld + 2 * c2;
+#pragma unroll
+        for (int r = 0; r < 32; r++) blk[r] = *reinterpret_cast<const d2_t *>(lp + (long)r * ld);
+    }
+    for (int j = 0; j < k; ++j) {
+        if (j + 1 < k) {
+            const double *lp = L + (long)(k * 128 + 32 * qd) * ld + (j + 1) * 128 + 2 * c2;
+#pragma unroll
+            for (int r = 0; r < 32; r++) nblk[r] = *reinterpret_cast<const d2_t *>(lp + (long)r * ld);
+        }
+        if (tid < 128) {   // wait for z_j
+            const unsigned long long *zp = reinterpret_cast<const unsigned long long *>(Z) + j * 128 + tid;
+            unsigned long long b;
+            int spin = 0;
+            do {
+                b = (spin & 1023) == 1023
+                        ? __hip_atomic_fetch_or(const_cast<unsigned long long *>(zp), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                        : __hip_atomic_load(zp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b == BS_UNSET) __builtin_amdgcn_s_sleep(2);
+            } while (b == BS_UNSET && ++spin < BS_SPIN_MAX);
+            zj[j & 1][tid] = __longlong_as_double((long long)b);
+        }
+        __syncthreads();
+        const d2_t z = *reinterpret_cast<const d2_t *>(&zj[j & 1][2 * c2]);
+#pragma unroll
+        for (int r = 0; r < 32; r++) acc[r] += blk[r].x * z.x + blk[r].y * z.y;
+#pragma unroll
+        for (int r = 0; r < 32; r++) blk[r] = nblk[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 32; r++) red[32 * qd + r][c2] = acc[r];
+    __syncthreads();
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 32; c++) s += red[di][32 * dh + c];
+        part[dh][di] = s;
+    }
+    __syncthreads();
+    double out = 0.0;
+#pragma unroll
+    for (int c = 0; c < 64; c++) {
+        const int cc = 64 * dh + c;
+        out += dinv[c] * (bk[cc] - (part[0][cc] + part[1][cc]));
+    }
+    __syncthreads();                 // every read of part[] is done before it is reused for the two halves of `out`
+    if (dh == 1) part[0][di] = out;
+    __syncthreads();
+    if (dh == 0) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(out + part[0][di]);
+        if (bits == BS_UNSET) bits = 0x7FF8000000000000ull;
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(Z) + k * 128 + di, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
     const int k = blockIdx.x;
     for (int idx = threadIdx.x; idx < 128 * 128; idx += blockDim.x) {
@@ -549,6 +636,17 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
     else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
     else hipLaunchKernelGGL(backsolve_chain_kernel<8>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
+    return hipGetLastError();
+}
+
+// x = (L L')^-1 b for one right-hand side against the factor at hand: forward chain into `tmp`, backward chain into X
+// (both of length nfact; b, tmp, X distinct device vectors).
+hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
+    const int nb = nfact / 128;
+    HIPCHK(hipMemsetAsync(tmp, 0xFF, (size_t)nfact * sizeof(double), stream));
+    HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nfact * sizeof(double), stream));
+    hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
+    hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, tmp, (long)nfact, X, (long)nfact, nb, 1);
     return hipGetLastError();
 }
 

@@ -33,6 +33,11 @@ hipError_t launch_omega(hipStream_t, const DevProblem &, const uint8_t *, int, i
                         const double *, const double *, const double *, double, double *, double *);
 }  // namespace jaicov
 
+namespace jaicov {
+struct RefineBorder { double kappa[7]; double rk[7]; };
+hipError_t launch_residual_dd(hipStream_t, const double *, long, int, int, int, const double *, const double *, const double *,
+                              const double *, const double *, long, const RefineBorder &, double *, double *);
+}
 using namespace jaicov;
 
 static const double EPS53 = 1.1102230246251565e-16;   // Constant.EPS = 2^-53 (Constant.java:68-75)
@@ -163,6 +168,10 @@ struct jaicov_engine {
     std::string err = "";
     int device = 0;
     int flow_retries = 0;      // dataflow factorisations that were abandoned and repeated (solve)
+    int refine_steps = 1;      // iterative refinement of the step (refine.hip): engine option `refinement` / JAICOV_REFINE
+    double *d_Braw = nullptr, *d_refP = nullptr, *d_ref = nullptr;   // unscaled datum rows; partial-sum table; rhs | tmp | delta
+    size_t refP_len = 0;
+    double last_refine_correction = 0.0;   // max |correction| / max |dx| of the last refinement step (diagnostics)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;   // assembly: camera-side kernels on a side stream (assemble.hip)
     hipStream_t stream = nullptr;
     DevProblem p{};
@@ -218,6 +227,7 @@ struct jaicov_engine {
     hipEvent_t ev[10];
     bool pp_plain_ok = false;   // the point x point gather may store its strips (see PPGather::plain)
     hipEvent_t ev_first = nullptr, ev_all = nullptr;   // solve(): first panel's columns / whole matrix copied into the solver
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;       // solve(): device part of a refinement step
 };
 
 #define FAIL(e, code, msg)                 \
@@ -300,6 +310,9 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     if (e->ev_join) hipEventDestroy(e->ev_join);
     if (e->ev_first) hipEventDestroy(e->ev_first);
     if (e->ev_all) hipEventDestroy(e->ev_all);
+    if (e->ev_r0) hipEventDestroy(e->ev_r0);
+    if (e->ev_r1) hipEventDestroy(e->ev_r1);
+    if (e->d_refP) hipFree(e->d_refP);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -312,6 +325,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     HIPE(e, hipSetDevice(e->device));
     e->deterministic = e->opts.deterministic != 0;
     if (const char *dv = getenv("JAICOV_DETERMINISTIC")) e->deterministic = atoi(dv) != 0;
+    e->refine_steps = e->opts.refinement == 0 ? 1 : (e->opts.refinement < 0 ? 0 : std::min(e->opts.refinement, 4));
+    if (const char *rv = getenv("JAICOV_REFINE")) e->refine_steps = std::max(0, std::min(atoi(rv), 4));
     hipDeviceProp_t prop;
     HIPE(e, hipGetDeviceProperties(&prop, e->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -322,6 +337,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     HIPE(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
     HIPE(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
     HIPE(e, hipEventCreateWithFlags(&e->ev_all, hipEventDisableTiming));
+    HIPE(e, hipEventCreate(&e->ev_r0));
+    HIPE(e, hipEventCreate(&e->ev_r1));
 
     const int U = D->n_unknowns, d = D->rank_defect;
     e->U = U; e->d = d; e->datum_flags = D->datum_flags;
@@ -673,6 +690,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_B, true))) return rc;
     if ((rc = dalloc(e, (size_t)e->Upad, &e->d_dx, true))) return rc;
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_G, true))) return rc;
+    if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_Braw, true))) return rc;
+    if ((rc = dalloc(e, (size_t)3 * e->Upad, &e->d_ref, true))) return rc;
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_H, true))) return rc;
     if ((rc = dalloc(e, (size_t)8 * e->Upad, &e->d_F, true))) return rc;
     if ((rc = dalloc(e, (size_t)64, &e->d_E, true))) return rc;
@@ -1134,6 +1153,69 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     for (int c = 0; c < U; c++) dx_out[c] = c < d ? R[c] * kh[c] : e->h_V[c] * y[c];
     for (int c = 0; c < U; c++)
         if (!std::isfinite(dx_out[c])) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite step");
+    // ---- iterative refinement (refine.hip): residual of the unscaled bordered system in two-fold precision, one forward and
+    // one backward substitution with the factor at hand per step.  The correction of the border follows the same rank-d
+    // algebra as above with r_y = V rho_x, r_k = R rho_kappa:  delta0 = M^-1 (r_y + Bh' r_k),
+    // dk = S^-1 (Bh delta0 - r_k),  dy = delta0 - G^ dk.
+    float refine_ms = 0.f;
+    e->last_refine_correction = 0.0;
+    for (int step = 0; step < e->refine_steps && !e->sim_built; step++) {
+        const int nbk = Up / 128;
+        const size_t need = (size_t)nbk * nbk * 256;
+        if (e->refP_len < need) {
+            if (e->d_refP) hipFree(e->d_refP);
+            e->d_refP = nullptr; e->refP_len = 0;
+            HIPE(e, hipMalloc(&e->d_refP, need * sizeof(double)));
+            e->refP_len = need;
+        }
+        RefineBorder bd{};
+        for (int a = 0; a < d; a++) {
+            long double sacc = 0.0L;
+            for (int c = d; c < U; c++) sacc += (long double)e->hB[(size_t)a * Upad + c] * (long double)dx_out[c];
+            bd.kappa[a] = dx_out[a];
+            bd.rk[a] = (double)(-(long double)R[a] * sacc);
+        }
+        double *d_rhs = e->d_ref, *d_tmp = e->d_ref + Upad, *d_delta = e->d_ref + 2 * (size_t)Upad;
+        HIPE(e, hipEventRecord(e->ev_r0, e->stream));
+        if (d > 0 && step == 0)
+            HIPE(e, hipMemcpyAsync(e->d_Braw, e->hB.data(), (size_t)d * Upad * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPE(e, hipMemcpyAsync(e->d_dx, dx_out, (size_t)U * sizeof(double), hipMemcpyHostToDevice, e->stream));
+        HIPE(e, launch_residual_dd(e->stream, e->d_N, (long)Upad, U, d, Up, e->d_dx, e->d_n, e->d_V, e->d_Braw, e->d_B, (long)Upad,
+                                   bd, e->d_refP, d_rhs));
+        HIPE(e, slv.solve_rhs(d_rhs, d_tmp, d_delta));
+        HIPE(e, hipEventRecord(e->ev_r1, e->stream));
+        std::vector<double> dl((size_t)Up);
+        HIPE(e, hipMemcpyAsync(dl.data(), d_delta, dl.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        float ms1 = 0.f;
+        hipEventElapsedTime(&ms1, e->ev_r0, e->ev_r1);
+        refine_ms += ms1;
+        double dk[7] = {0, 0, 0, 0, 0, 0, 0};
+        if (d > 0) {
+            double tt[7];
+            for (int a = 0; a < d; a++) {
+                double sacc = 0.0;
+                for (int c = d; c < U; c++) sacc += Bh[(size_t)a * Upad + c] * dl[c];
+                tt[a] = sacc - bd.rk[a];
+            }
+            for (int a = 0; a < d; a++) {
+                double sacc = 0.0;
+                for (int b = 0; b < d; b++) sacc += Sinv[a * d + b] * tt[b];
+                dk[a] = sacc;
+            }
+        }
+        double cmax = 0.0, xmax = 0.0;
+        for (int c = d; c < U; c++) {
+            double dy = dl[c];
+            for (int a = 0; a < d; a++) dy -= X[(size_t)(1 + a) * vs + c] * dk[a];
+            const double corr = e->h_V[c] * dy;
+            if (!std::isfinite(corr)) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite refinement step");
+            dx_out[c] += corr;
+            cmax = std::max(cmax, fabs(corr)); xmax = std::max(xmax, fabs(dx_out[c]));
+        }
+        for (int a = 0; a < d; a++) dx_out[a] += R[a] * dk[a];
+        e->last_refine_correction = xmax > 0.0 ? cmax / xmax : 0.0;
+    }
     if (schur && e->sim_built) {
         // SIMULATION zeroes the right-hand side of the WHOLE system (BA:830-831 `n.zero()`): the eliminated exterior
         // orientations get no step either (their back substitution would use the real misclosures)
@@ -1217,7 +1299,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     hipEventElapsedTime(&ms, e->ev[1], e->ev[2]); e->timings[1] = ms;
     hipEventElapsedTime(&ms, e->ev[2], e->ev[3]); e->timings[2] = ms;
     hipEventElapsedTime(&ms, e->ev[4], e->ev[5]); e->timings[3] = ms;
-    hipEventElapsedTime(&ms, e->ev[5], e->ev[6]); e->timings[4] = ms;
+    hipEventElapsedTime(&ms, e->ev[5], e->ev[6]); e->timings[4] = ms + refine_ms;   // substitution + refinement steps
     hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); e->timings[5] = ms;
     hipEventElapsedTime(&ms, e->ev[0], e->ev[7]); e->timings[7] = ms;
     e->state = jaicov_engine::ST_SOLVED;

@@ -46,7 +46,8 @@ class EngineError(RuntimeError):
 class EngineOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("image_begin", C.c_int32),
                 ("image_end", C.c_int32), ("apply_shared", C.c_int32), ("assembly_mode", C.c_int32),
-                ("block_size", C.c_int32), ("reduced_reference_quirk", C.c_int32), ("deterministic", C.c_int32), ("reserved", C.c_int32 * 6)]
+                ("block_size", C.c_int32), ("reduced_reference_quirk", C.c_int32), ("deterministic", C.c_int32), ("refinement", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class EstimateOptions(C.Structure):
@@ -127,7 +128,7 @@ class Engine:
     """One engine per adjustment (``BundleAdjustment`` is single-shot: BundleAdjustment.java:203)."""
 
     def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0,
-                 reduced_reference_quirk: bool = False, deterministic: bool = False):
+                 reduced_reference_quirk: bool = False, deterministic: bool = False, refinement: int = 0):
         self.L = load_library()
         self.fp = fp
         self.U = fp.n_unknowns
@@ -140,6 +141,7 @@ class Engine:
         opts.assembly_mode = int(assembly_mode)
         opts.reduced_reference_quirk = int(reduced_reference_quirk)
         opts.deterministic = int(deterministic)
+        opts.refinement = int(refinement)      # 0 = default (one step of iterative refinement per solve), < 0 = none, k = k steps
         self._h = C.c_void_p()
         rc = self.L.jaicov_neq_create(C.byref(self._desc), C.byref(opts), C.byref(self._h))
         if rc != 0:

@@ -163,7 +163,13 @@ typedef struct jaicov_engine_options {
                                       differences in N from run to run, which cond(N) ~ 1e9 turns into ~1e-9 in Qxx on the smallest
                                       test scenes.  Costs 1.4 ms per pass at config 4 (assembly 3.5 -> 5.0 ms: every wave of the gather then
                                       walks all images of its point).  JAICOV_DETERMINISTIC=0/1 overrides.                              */
-    int32_t  reserved[6];
+    int32_t  refinement;           /* iterative refinement of the step in jaicov_neq_solve: 0 = default (ONE step), < 0 = none, k > 0 = k steps
+                                      (at most 4).  A step computes the residual n - N dx (and the datum border's) of the unscaled system
+                                      in two-fold precision on the device and solves for the correction with the factor at hand (one forward
+                                      and one backward substitution, csrc/refine.hip): the error of dx against the exact solution of the
+                                      assembled system falls from cond * eps (2.6e-8 at config 4, where the reference's dspsv, MX:338-353, is
+                                      at 3.6e-9) to ~1e-12.  Costs ~1 ms per pass at config 4.  JAICOV_REFINE=k overrides.                  */
+    int32_t  reserved[5];
 } jaicov_engine_options;
 
 typedef struct jaicov_engine jaicov_engine;
