@@ -29,6 +29,8 @@ hipError_t launch_schur_backsub(hipStream_t, const DevProblem &, const int32_t *
                                 const double *, double *);
 hipError_t launch_shared_groups(hipStream_t, const DevProblem &, const double *, double, double *, double *,
                                 const double *, double *);
+hipError_t launch_schur_expand_f(hipStream_t, const DevProblem &, const int32_t *, int, const double *, const double *, const double *,
+                                 const double *, double *, long);
 hipError_t launch_omega(hipStream_t, const DevProblem &, const uint8_t *, int, int, const int32_t *, int, int,
                         const double *, const double *, const double *, double, double *, double *);
 }  // namespace jaicov
@@ -122,6 +124,34 @@ __global__ __launch_bounds__(256) void qfix_kernel(double *__restrict__ Q, long 
     Q[(long)i * ld + j] = v;
 }
 
+// Full cofactor matrix from the inverse of the EO-reduced system (JAICOV_INVERT_FULL_EXPANDED):
+//   rows / columns < e0        Qr (the reduced inverse, final: unscaled, border included)
+//   EO row e0 + r, column < e0   T1[r][c] = -(F Q_RR)[r][c]
+//   EO row, EO column            T2 = -(T1 F') (lower) + N_EE^-1 on the 6 x 6 diagonal blocks, N_EE^-1 = L_E^-T L_E^-1
+// lower part (j <= i) of the leading U rows of Qf.
+__global__ __launch_bounds__(256) void expand_cofactor_kernel(double *__restrict__ Qf, long ldf, int U, int e0,
+                                                              const double *__restrict__ Qr, long ldr,
+                                                              const double *__restrict__ T1, long ld1,
+                                                              const double *__restrict__ T2, long ld2,
+                                                              const double *__restrict__ Linv) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j > i || i >= U) return;
+    double v;
+    if (i < e0) v = Qr[(long)i * ldr + j];
+    else if (j < e0) v = T1[(long)(i - e0) * ld1 + j];
+    else {
+        const int ri = i - e0, rj = j - e0;
+        v = T2[(long)ri * ld2 + rj];
+        if (ri / 6 == rj / 6) {
+            const double *Li = Linv + (long)(ri / 6) * 36;
+            const int a = ri % 6, b = rj % 6;
+            for (int m = a > b ? a : b; m < 6; m++) v += Li[6 * m + a] * Li[6 * m + b];
+        }
+    }
+    Qf[(long)i * ldf + j] = v;
+}
+
 // row-major lower square <-> packed ('U' column-major == row-major lower packed)
 __global__ __launch_bounds__(256) void pack_kernel(const double *__restrict__ M, long ld, int U, double *__restrict__ ap) {
     const int j = blockIdx.x * 256 + threadIdx.x;
@@ -196,6 +226,8 @@ struct jaicov_engine {
     bool dense_mode = false;
     double dm_flops_per_pass = 0.0, dm_stat_passes = 0.0, dm_stat_ms = 0.0, dm_stat_flops = 0.0;
     int inverse_mode_next = 0;       // JAICOV_INVERT_* announced for the solve after the next build
+    bool all_images = true;          // this engine accumulates every image (not a shard): FULL_EXPANDED needs every image's U, L_E
+    bool solver_has_Q = false;       // solver.Q alone is allocated (target of the expansion)
     int q_order = 0;                 // order of the cofactor matrix on the device (U, or e0 for the reduced one)
     bool q_reduced = false, solverS_has_inverse = false;
     std::vector<int> h_blk_images;   // image of every block handled by this engine
@@ -388,6 +420,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     int ib = 0, ie = D->n_images;
     if (opts && opts->image_begin >= 0 && opts->image_end >= 0) { ib = opts->image_begin; ie = opts->image_end; }
     if (ib < 0 || ie > D->n_images || ib > ie) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "bad image range");
+    e->all_images = ib == 0 && ie == D->n_images;
     {
         const int32_t *b = std::lower_bound(D->ip_image, D->ip_image + D->n_image_points, ib);
         const int32_t *en = std::lower_bound(D->ip_image, D->ip_image + D->n_image_points, ie);
@@ -929,21 +962,33 @@ static int ensure_inverse_buffers(jaicov_engine *e, bool reduced_system) {
     if (has_inv) return JAICOV_OK;
     const size_t sq = (size_t)slv.n * slv.ld * sizeof(double);
     HIPE(e, hipMalloc(&slv.W, sq));
-    HIPE(e, hipMalloc(&slv.Q, sq));
+    if (!slv.Q) HIPE(e, hipMalloc(&slv.Q, sq));
     has_inv = true;
     return JAICOV_OK;
 }
 
+// FULL_EXPANDED is FULL wherever the expansion cannot be done: no EO pre-elimination, or an engine that sees a shard of the images
+static int effective_invert(const jaicov_engine *e, int invert) {
+    if (invert == JAICOV_INVERT_FULL_EXPANDED && !(e->schur_ok && e->all_images && !getenv("JAICOV_FULL_LITERAL"))) return JAICOV_INVERT_FULL;
+    return invert;
+}
+
 extern "C" int jaicov_neq_prepare_inverse(jaicov_engine *e, int inverse_follows) {
     if (!e) return JAICOV_ERR_BAD_ARGUMENT;
-    if (inverse_follows < 0 || inverse_follows > JAICOV_INVERT_REDUCED) return JAICOV_ERR_BAD_ARGUMENT;
+    if (inverse_follows < 0 || inverse_follows > JAICOV_INVERT_FULL_EXPANDED) return JAICOV_ERR_BAD_ARGUMENT;
+    inverse_follows = effective_invert(e, inverse_follows);
     e->inverse_mode_next = inverse_follows;
     // the inverse's buffers are allocated HERE, when the final pass is announced (BA:250: known before the build), not inside
     // the solve: hipMalloc of 2 x 1.8 .. 2.6 GB cost the first inverting solve 45 ms at config 4
     if (inverse_follows != JAICOV_INVERT_NONE) {
         HIPE(e, hipSetDevice(e->device));
-        const bool reduced = e->schur_ok && inverse_follows == JAICOV_INVERT_REDUCED && e->solverS_ready;
-        return ensure_inverse_buffers(e, reduced);
+        const bool reduced = e->schur_ok && (inverse_follows == JAICOV_INVERT_REDUCED || inverse_follows == JAICOV_INVERT_FULL_EXPANDED) && e->solverS_ready;
+        int rc = ensure_inverse_buffers(e, reduced);
+        if (rc) return rc;
+        if (inverse_follows == JAICOV_INVERT_FULL_EXPANDED && !e->solver.Q) {     // the expanded matrix lives in the full-order solver's Q
+            HIPE(e, hipMalloc(&e->solver.Q, (size_t)e->solver.n * e->solver.ld * sizeof(double)));
+            e->solver_has_Q = true;
+        }
     }
     return JAICOV_OK;
 }
@@ -1038,7 +1083,10 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     if (e->state != jaicov_engine::ST_BUILT) FAIL(e, JAICOV_ERR_BAD_STATE, "build first");
     HIPE(e, hipSetDevice(e->device));
     const bool schur = e->schur_active;
-    if (invert < 0 || invert > JAICOV_INVERT_REDUCED) return JAICOV_ERR_BAD_ARGUMENT;
+    if (invert < 0 || invert > JAICOV_INVERT_FULL_EXPANDED) return JAICOV_ERR_BAD_ARGUMENT;
+    invert = effective_invert(e, invert);
+    if (invert == JAICOV_INVERT_FULL_EXPANDED && !schur) invert = JAICOV_INVERT_FULL;     // the system at hand was assembled unreduced
+    const bool expand = invert == JAICOV_INVERT_FULL_EXPANDED;
     if (schur && invert == JAICOV_INVERT_FULL)
         FAIL(e, JAICOV_ERR_BAD_STATE, "the normal equations were assembled with the EO blocks pre-eliminated: call "
                                       "jaicov_neq_prepare_inverse(e, JAICOV_INVERT_FULL) before the build whose solve shall invert");
@@ -1057,6 +1105,10 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     if (invert) {   // normally done by prepare_inverse(); a host that did not announce the final pass pays the allocation here
         const int rc_inv = ensure_inverse_buffers(e, schur);
         if (rc_inv) return rc_inv;
+        if (expand && !e->solver.Q) {
+            HIPE(e, hipMalloc(&e->solver.Q, (size_t)e->solver.n * e->solver.ld * sizeof(double)));
+            e->solver_has_Q = true;
+        }
     }
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
     HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1280,11 +1332,32 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         }
         hipLaunchKernelGGL(qfix_kernel, dim3((Up + 255) / 256, Up), dim3(256), 0, e->stream, slv.Q, ld, U, Upad, d,
                            e->d_V, e->d_G + vs, (long)vs, e->d_H, e->d_F, e->d_E, Up);
+        if (expand) {
+            // ---- the full cofactor matrix from the reduced one (schur.hip, blk_expand_f_kernel): workspace = W of the reduced
+            //      solver, free again after lauum():  F [6I pad][Up] | T1 = -F Q_RR [6I pad][Up] | T2 = -T1 F' [6I pad][6I pad]
+            const int I6 = 6 * e->p.n_images, I6p = ((I6 + 127) / 128) * 128;
+            if ((size_t)I6p * ((size_t)2 * Up + I6p) > (size_t)slv.n * slv.ld)
+                FAIL(e, JAICOV_ERR_UNSUPPORTED, "FULL_EXPANDED: more exterior orientations than the workspace holds; use JAICOV_INVERT_FULL");
+            double *Fm = slv.W, *T1 = Fm + (size_t)I6p * Up, *T2 = T1 + (size_t)I6p * Up;
+            HIPE(e, hipMemsetAsync(Fm, 0, (size_t)I6p * Up * sizeof(double), e->stream));
+            HIPE(e, launch_schur_expand_f(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->sb.U, e->sb.Linv, e->sb.G, Fm, (long)Up));
+            HIPE(e, slv.symmetrize(slv.Q));
+            GemmArgs g1{};
+            g1.A = Fm; g1.lda = Up; g1.B = slv.Q; g1.ldb = ld; g1.C = T1; g1.ldc = Up;
+            g1.M = I6p; g1.N = Up; g1.K = Up; g1.alpha = -1.0; g1.beta = 0.0; g1.kmode = KMODE_FULL;
+            HIPE(e, gemm_f64(e->stream, LAY_KC, LAY_KC, g1));             // Q_RR symmetric: F Q_RR = F Q_RR'
+            GemmArgs g2{};
+            g2.A = T1; g2.lda = Up; g2.B = Fm; g2.ldb = Up; g2.C = T2; g2.ldc = I6p;
+            g2.M = I6p; g2.N = I6p; g2.K = Up; g2.alpha = -1.0; g2.beta = 0.0; g2.kmode = KMODE_FULL; g2.lower_only = 1;
+            HIPE(e, gemm_f64(e->stream, LAY_KC, LAY_KC, g2));
+            hipLaunchKernelGGL(expand_cofactor_kernel, dim3((e->U + 255) / 256, e->U), dim3(256), 0, e->stream, e->solver.Q, e->solver.ld,
+                               e->U, e->e0, slv.Q, ld, T1, (long)Up, T2, (long)I6p, e->sb.Linv);
+        }
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
         e->have_Q = true;
-        e->q_reduced = schur;
-        e->q_order = U;
+        e->q_reduced = schur && !expand;
+        e->q_order = expand ? e->U : U;
     } else {
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
@@ -1471,6 +1544,9 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
     if (!e || !o || !res || o->struct_size != sizeof(jaicov_estimate_options)) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
     const double SQRT_EPS = sqrt(EPS53);
+    if (o->invert < 0 || o->invert > JAICOV_INVERT_FULL_EXPANDED) return JAICOV_ERR_BAD_ARGUMENT;
+    // MatrixInversion.FULL: all of Qxx, computed from the EO-reduced system where the engine can (jaicov_neq.h, FULL_EXPANDED)
+    const int inv_mode = o->invert == JAICOV_INVERT_FULL ? JAICOV_INVERT_FULL_EXPANDED : o->invert;
     const int max_iter = o->max_iterations;
     auto t0 = std::chrono::steady_clock::now();
     bool deriveFirst = o->lambda0 > 0;
@@ -1488,13 +1564,13 @@ extern "C" int jaicov_neq_estimate(jaicov_engine *e, const jaicov_estimate_optio
         maxAbsDx = 0.0;
         iter = max_iter - runs;
         if (deriveFirst) { adapted = damping; deriveFirst = false; }
-        jaicov_neq_prepare_inverse(e, isEstimated ? o->invert : JAICOV_INVERT_NONE);
+        jaicov_neq_prepare_inverse(e, isEstimated ? inv_mode : JAICOV_INVERT_NONE);
         rc = jaicov_neq_build(e, sigma2, adapted, o->simulation);
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
         if (rc) { state = rc == JAICOV_ERR_BAD_ARGUMENT || rc > 0 ? -2 : -1; break; }
         if (e->cancel.exchange(0)) { state = -1; rc = JAICOV_OK; break; }       // BA:240-245: INTERRUPT, flag cleared
         complete = isEstimated;
-        rc = jaicov_neq_solve(e, complete ? o->invert : JAICOV_INVERT_NONE, dx.data());
+        rc = jaicov_neq_solve(e, complete ? inv_mode : JAICOV_INVERT_NONE, dx.data());
         if (rc == JAICOV_ERR_OUT_OF_MEMORY) { state = -7; break; }
         if (rc) { state = (rc > 0 || rc == JAICOV_ERR_BAD_ARGUMENT) ? -2 : -1; break; }
         bool rejected = false;

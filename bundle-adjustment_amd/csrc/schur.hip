@@ -335,6 +335,64 @@ __global__ __launch_bounds__(256) void blk_diagcorr_det_kernel(DevProblem p, PPG
     diagcorr[col] += s;
 }
 
+// F = N_EE^-1 N_ER, one 6-row band per image, dense [6 * images (padded)][ldf]:  F_img = L_E^-T (U' A_r)  (U' = L_E^-1 A_e' P).
+// With Q_RR = the inverse of the reduced system the rest of the full cofactor matrix follows from it (engine.hip, solve with
+// JAICOV_INVERT_FULL_EXPANDED):  Q_ER = -F Q_RR,  Q_EE = N_EE^-1 - Q_ER F'.  One workgroup per image block; a point is seen
+// once per image, so every entry of F has one writer.  F must be zero beforehand.
+__global__ __launch_bounds__(256) void blk_expand_f_kernel(DevProblem p, const int32_t *__restrict__ blk_list,
+                                                           const double *__restrict__ rowsA, const double *__restrict__ Ubuf,
+                                                           const double *__restrict__ Linv, const double *__restrict__ G,
+                                                           double *__restrict__ F, long ldf) {
+    __shared__ double Li[36];
+    const int tid = threadIdx.x;
+    const int g = blk_list[blockIdx.x];
+    const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb;
+    const long S = p.n_ip;
+    const int img = p.ip_image[ipb], cam = p.image_camera[img];
+    if (tid < 36) Li[tid] = Linv[(long)img * 36 + tid];
+    __syncthreads();
+    double *Fi = F + (long)(6 * img) * ldf;
+    for (int q = tid; q < mp; q += 256) {
+        const int ip = ipb + q, pt = p.ip_point[ip];
+        const double *u0 = Ubuf + ((long)2 * ip) * 8, *u1 = u0 + 8;
+        for (int b = 0; b < 3; b++) {
+            const int col = p.point_col[3 * pt + b];
+            if (col < 0) continue;
+            const double a0 = rowsA[(long)(2 * b) * S + ip], a1 = rowsA[(long)(2 * b + 1) * S + ip];
+            double y[6];
+#pragma unroll
+            for (int j = 0; j < 6; j++) y[j] = u0[j] * a0 + u1[j] * a1;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                double f = 0.0;
+#pragma unroll
+                for (int j = k; j < 6; j++) f += Li[6 * j + k] * y[j];      // (L^-T y)[k] = sum_j Linv[j][k] y[j]
+                Fi[(long)k * ldf + col] = f;
+            }
+        }
+    }
+    const int jb = p.cam_dist_begin[cam], ncr = 3 + p.cam_dist_begin[cam + 1] - jb;
+    for (int c = tid; c < ncr; c += 256) {
+        const int col = c < 3 ? p.io_col[3 * cam + c] : p.dist_col[jb + c - 3];
+        if (col < 0) continue;
+        const double *Gi = G + (long)img * 6 * SCHUR_GLD;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            double f = 0.0;
+#pragma unroll
+            for (int j = k; j < 6; j++) f += Li[6 * j + k] * Gi[j * SCHUR_GLD + c];
+            Fi[(long)k * ldf + col] = f;
+        }
+    }
+}
+
+hipError_t launch_schur_expand_f(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, const double *rowsA,
+                                 const double *Ubuf, const double *Linv, const double *G, double *F, long ldf) {
+    if (n_list <= 0) return hipSuccess;
+    hipLaunchKernelGGL(blk_expand_f_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, Ubuf, Linv, G, F, ldf);
+    return hipGetLastError();
+}
+
 hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double lambda, double *Ubuf, double *Linv, double *G,

@@ -32,6 +32,7 @@ EXPORTS = [
 
 KROW = 32  # 12 + JAICOV_MAX_DIST_PER_CAMERA
 INVERT_NONE, INVERT_FULL, INVERT_REDUCED = 0, 1, 2   # MatrixInversion (BundleAdjustment.java:65-70)
+INVERT_FULL_EXPANDED = 3     # all of Qxx like FULL, computed from the EO-reduced system (jaicov_neq.h)
 
 _pd = C.POINTER(C.c_double)
 _pi = C.POINTER(C.c_int32)

@@ -358,7 +358,8 @@ EstimationStateType BundleAdjustment::estimateModel() {
     // full inverse (a superset of what the reference leaves in N).
     const bool wantInverse = inversion_ != MatrixInversion::NONE;
     const int invertMode = inversion_ == MatrixInversion::NONE ? JAICOV_INVERT_NONE
-                         : inversion_ == MatrixInversion::FULL ? JAICOV_INVERT_FULL : JAICOV_INVERT_REDUCED;
+                         : inversion_ == MatrixInversion::FULL ? JAICOV_INVERT_FULL_EXPANDED : JAICOV_INVERT_REDUCED;   // FULL: all of Qxx,
+    // expanded from the inverse of the EO-reduced system where the engine can pre-eliminate (jaicov_neq.h), else the plain full inverse
     std::vector<double> dx((size_t)std::max(U, 1));
     EstimationStateType status = EstimationStateType::BUSY;
     do {

@@ -209,6 +209,14 @@ int jaicov_neq_accumulate2(jaicov_engine *e, double sigma2apriori, double lambda
 #define JAICOV_INVERT_NONE    0
 #define JAICOV_INVERT_FULL    1
 #define JAICOV_INVERT_REDUCED 2
+/* FULL_EXPANDED: the same matrix as FULL (order U, all unknowns), computed from the EO-reduced system instead of from a
+ * factorisation of the unreduced one: Q_RR = S^-1 (the REDUCED inverse), Q_ER = -F Q_RR, Q_EE = N_EE^-1 - Q_ER F' with
+ * F = N_EE^-1 N_ER, N_EE block diagonal 6 x 6 per image (the block formulas behind BA:1197-1453).  The build keeps the EO
+ * pre-elimination (jaicov_neq_get_normal returns the reduced system).  At config 4 it is both faster (no order-18 014 factorisation)
+ * and ~50x more accurate than FULL (profiles/r03_cfg4_accuracy.json: the unreduced Cholesky loses 2e-7 where the reduced one
+ * loses 4e-9).  jaicov_neq_estimate and the host mirror's estimateModel() use it for MatrixInversion.FULL; where the engine cannot
+ * pre-eliminate, or holds only a shard of the images, it is served as FULL.  JAICOV_FULL_LITERAL=1 forces FULL everywhere.        */
+#define JAICOV_INVERT_FULL_EXPANDED 3
 /* Announces the `invert` value of the solve after the NEXT build (the final pass, BA:252-280): FULL makes that build
  * assemble the full system instead of the EO-reduced one.  estimateModel knows this before it builds (BA:250
  * estimateCompleteModel = isEstimated).                                                                            */

@@ -109,3 +109,59 @@ def test_refined_step_of_the_reduced_path_matches_the_full_system(oracle_mod):
     z = exact_solution(packed_to_full(N, U), n)
     print(f"reduced path vs exact solution of the full system: {rel(dx, z):.2e}")
     assert rel(dx, z) < 1e-10                              # cond ~ 5e5: the two assemblies differ by ~1e-16 * cond
+
+
+@pytest.mark.parametrize("free_network", [False, True])
+def test_full_cofactor_expanded_from_the_reduced_inverse(oracle_mod, free_network):
+    """JAICOV_INVERT_FULL_EXPANDED: all of Qxx = K^-1 (border, points, interior orientation, distortion AND exterior orientations)
+    from the inverse of the EO-reduced system by the block formulas Q_ER = -F Q_RR, Q_EE = N_EE^-1 - Q_ER F' (schur.hip), against
+    the reference's dspsv + dsptri on the full bordered system -- with and without a datum border."""
+    if free_network:
+        fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=0, scale_bar=True)
+    else:
+        fp = scene.make_scene(8, 60, 40, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, True)
+    U, d = fp.n_unknowns, fp.rank_defect
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_FULL_EXPANDED)
+    eng.build(s2, 0.0)
+    assert eng.reduced_order() == U - 6 * fp.n_images          # the build kept the EO pre-elimination
+    dx = eng.solve(engine.INVERT_FULL_EXPANDED)
+    np.testing.assert_allclose(dx[d:], dxo[d:], rtol=0, atol=1e-9 * np.abs(dxo[d:]).max())
+    assert eng.cofactor_order() == U
+    Q = packed_to_full(eng.get_cofactor(), U)
+    Qref = packed_to_full(Qo, U)
+    sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
+    err = (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max()
+    print(f"expanded full cofactor vs dsptri (correlation-scaled): {err:.2e}; border block {np.abs(Q - Qref)[:d, :].max() if d else 0.0:.2e}")
+    assert err < 1e-9
+    assert np.abs(Q - Qref).max() <= 1e-8 * np.abs(Qref).max()      # border rows (multipliers' cofactors) included
+    e0 = U - 6 * fp.n_images
+    idx = np.array([d, e0 - 1, e0, e0 + 7, U - 1, e0 + 6], np.int32)
+    np.testing.assert_array_equal(eng.get_cofactor_sub(idx), Q[np.ix_(idx, idx)])
+    # the literal FULL route (factorisation of the unreduced system) gives the same matrix
+    eng.prepare_inverse(engine.INVERT_FULL); eng.build(s2, 0.0); eng.solve(engine.INVERT_FULL)
+    Ql = packed_to_full(eng.get_cofactor(), U)
+    assert (np.abs(Ql - Q)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
+    eng.close()
+
+
+def test_expanded_mode_falls_back_to_full_where_it_cannot_apply(oracle_mod):
+    """No dense image blocks -> no EO pre-elimination: FULL_EXPANDED is served as FULL (like REDUCED is, jaicov_neq.h)."""
+    fp = scene.config("tiny")
+    o = oracle_mod.Oracle(fp)
+    dxo, Qo, _, _ = o.step(fp.values, fp.sigma2apriori, 0.0, True)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_FULL_EXPANDED)
+    eng.build(fp.sigma2apriori, 0.0)
+    eng.solve(engine.INVERT_FULL_EXPANDED)
+    U = fp.n_unknowns
+    assert eng.cofactor_order() == U and eng.reduced_order() == U
+    Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
+    sd = np.sqrt(np.abs(np.diag(Qref)))
+    assert (np.abs(Q - Qref) / np.outer(sd, sd)).max() < 1e-9
+    eng.close()

@@ -1,0 +1,88 @@
+"""The whole loop, run to the REFERENCE's termination criterion at BASELINE configs 3 and 4, against the oracle run to the same
+criterion (missing 1 + 2).
+
+BundleAdjustment.java:327-353: passes run until max|dx| <= sqrt(eps) = 1.0537e-8, then ONE more pass with the inverse
+(BA:250-281).  Fixtures: tests/golden/cfg3/cfg3_converged.* (make_cfg3_golden.py: oracle_estimate, 27 s) and
+tests/golden/cfg4/cfg4_converged.* (make_cfg4_converged.py: the oracle's run at the headline size continued from the two
+passes of cfg4_oracle.npz to termination, ~2 h of one core).
+
+What is asserted: state ERROR_FREE_ESTIMATION, the SAME number of passes as the reference algorithm took, last max|dx| below the
+criterion, the converged parameters within 1e-9 (north_star) of the oracle's, Omega, sigma0^2 and every diagonal entry of Qxx at
+the converged point.  Default and deterministic assembly, MatrixInversion FULL and REDUCED.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import engine, scene
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SQRT_EPS = 1.0536712127723509e-8       # Math.sqrt(Constant.EPS)
+
+
+def load(cfg):
+    p = os.path.join(G, cfg, f"{cfg}_converged")
+    if not os.path.exists(p + ".npz"):
+        pytest.skip(f"{p}.npz not generated")
+    return dict(np.load(p + ".npz")), json.load(open(p + ".json"))
+
+
+def relative_parameter_error(fp, got, ref):
+    """object coordinates and projection centres against the extent of the object (2 000 mm), every other parameter against its
+    own magnitude (floor 1.0) -- the measure test_gpu_fullsize.py uses"""
+    P3, I6 = 3 * fp.n_points, 6 * fp.n_images
+    den = np.maximum(np.abs(ref), 1.0)
+    den[:P3] = 2000.0
+    den[-I6:].reshape(-1, 6)[:, :3] = 2000.0
+    return float((np.abs(got - ref) / den).max())
+
+
+def run_to_termination(fp, z, meta, invert, deterministic, qtol, check_values=1e-9):
+    eng = engine.Engine(fp, deterministic=deterministic)
+    values, res = eng.estimate(invert=invert)
+    try:
+        assert res.state == 1                                              # ERROR_FREE_ESTIMATION
+        assert res.iterations == meta["iteration_step"], (res.iterations, meta["iteration_step"], res.max_abs_dx)
+        assert res.max_abs_dx <= SQRT_EPS
+        err = relative_parameter_error(fp, values, z["values"])
+        assert err < check_values, err
+        assert abs(res.omega - meta["omega"]) <= 1e-9 * meta["omega"]
+        k = eng.cofactor_order()
+        assert k == (fp.n_unknowns if invert == engine.INVERT_FULL else eng.reduced_order())
+        Q = eng.get_cofactor()
+        idx = np.arange(k, dtype=np.int64)
+        dq = float(np.abs(Q[idx * (idx + 3) // 2] / z["diagQ"][:k] - 1.0).max())
+        del Q
+        cols = z["sample_cols"]; keep = cols < k
+        Qs = eng.get_cofactor_sub(cols[keep].astype(np.int32))
+        ref = z["Qsample"][np.ix_(keep, keep)]
+        sd = np.sqrt(np.abs(np.diag(ref)))
+        cq = float((np.abs(Qs - ref) / np.outer(sd, sd)).max())
+        assert dq < qtol and cq < qtol, (dq, cq)
+        return err, dq, cq, res
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("invert", [engine.INVERT_FULL, engine.INVERT_REDUCED])
+def test_config3_runs_to_the_references_termination(invert, deterministic):
+    z, meta = load("cfg3")
+    fp = scene.config("cfg3")
+    # cond(V N V) ~ 4e8 here; Qxx against dsptri: achieved 2e-9 (diag) / 3e-9 (correlation-scaled sample)
+    err, dq, cq, res = run_to_termination(fp, z, meta, invert, deterministic, qtol=2e-8)
+    print(f"cfg3 invert={invert} det={deterministic}: iterations {res.iterations}, max|dx| {res.max_abs_dx:.2e}, parameters {err:.2e}, "
+          f"diag Qxx {dq:.2e}, sample {cq:.2e}")
+
+
+@pytest.mark.parametrize("deterministic", [False, True])
+@pytest.mark.parametrize("invert", [engine.INVERT_FULL, engine.INVERT_REDUCED])
+def test_config4_runs_to_the_references_termination(cfg4_scene, invert, deterministic):
+    z, meta = load("cfg4")
+    # Qxx at cond ~ 1e9: the floor set by the assembly's rounding is stated in DESIGN.md (profiles/r03_cfg4_accuracy.json)
+    err, dq, cq, res = run_to_termination(cfg4_scene, z, meta, invert, deterministic, qtol=1e-6)
+    print(f"cfg4 invert={invert} det={deterministic}: iterations {res.iterations}, max|dx| {res.max_abs_dx:.2e}, parameters {err:.2e}, "
+          f"diag Qxx {dq:.2e}, sample {cq:.2e}")
