@@ -289,12 +289,14 @@ def main():
         for rep in range(2):
             sync()
             t1 = time.perf_counter()
+            # MatrixInversion.FULL as estimate() / estimateModel() run it: all of Qxx expanded from the inverse of the EO-reduced
+            # system (JAICOV_INVERT_FULL_EXPANDED); a sharded engine holds only its images' EO blocks and takes the literal route
             if use_dist:
                 dx = distributed.sharded_step(eng, dist, torch.device("cuda", local), s2, invert=engine.INVERT_FULL)
             else:
-                eng.prepare_inverse(engine.INVERT_FULL)
+                eng.prepare_inverse(engine.INVERT_FULL_EXPANDED)
                 eng.build(s2, 0.0)
-                dx = eng.solve(engine.INVERT_FULL)
+                dx = eng.solve(engine.INVERT_FULL_EXPANDED)
             om = distributed.sharded_omega(eng, dist, torch.device("cuda", local), s2, dx) if use_dist else eng.omega(s2, dx)
             sync()
             if rank == 0:
@@ -304,6 +306,16 @@ def main():
         # final pass of MatrixInversion.REDUCED / PRE_ELIMINATION (BA:261-267): cofactor matrix of the border, points,
         # interior orientation and distortion only = inverse of the EO-reduced system (the second run is reported,
         # the first one allocates the inverse's buffers)
+        for rep in range(0 if use_dist else 2):     # the literal route: factorisation + inverse of the unreduced system (order U)
+            sync()
+            t4 = time.perf_counter()
+            eng.prepare_inverse(engine.INVERT_FULL)
+            eng.build(s2, 0.0)
+            eng.solve(engine.INVERT_FULL)
+            sync()
+            if rank == 0:
+                out["final_pass_literal_full_ms"] = 1e3 * (time.perf_counter() - t4)
+                out["final_pass_literal_full_stage_ms"] = eng.timings()
         for rep in range(0 if a.iterations_only else 2):
             sync()
             t2 = time.perf_counter()

@@ -45,6 +45,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "dense.h"
@@ -650,16 +651,19 @@ __device__ __forceinline__ void chain_solve_update(double *Tg, long ld, long lon
     const double *Cg = Tg + 128;
     d4_t y[8][2], cacc[9];
     chain_tile_load(Tg, ld, y, tid);
-#pragma unroll
-    for (int i = 0; i < 9; i++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) cacc[i][r] = Cg[(long)(16 * CHAIN_TILE_R(i) + l4 + 4 * r) * ld + 16 * CHAIN_TILE_Q(i) + l15];
     if (tr) {
         drain_stores();
         tr[5] = wall_clock64();
     }
     chain_tile_solve(y, S, Wd, tid);
     if (tr) tr[6] = wall_clock64();
+    // the diagonal tile (c+1, c+1) is fetched only now: loaded before the solve its 72 registers joined the solve's in one
+    // allocation and the chain loop spilled (28 VGPRs).  Its latency hides behind the write-through stores of L[c+1][c] and the
+    // two barriers that follow.
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cacc[i][r] = Cg[(long)(16 * CHAIN_TILE_R(i) + l4 + 4 * r) * ld + 16 * CHAIN_TILE_Q(i) + l15];
     chain_tile_store(Tg, ld, y, tid);
     if (tr) tr[3] = wall_clock64();
     __syncthreads();          // every wave has read L_cc and Wd for the last time
@@ -708,6 +712,121 @@ __device__ __forceinline__ void chain_factor(double *Acc, long ld, int *info, in
     }
 }
 
+// The companion roles of the chain kernel as REAL calls (noinline): inlined, their register appetite (the inverse wants most of
+// the 512) joined the chain role's in one allocation and the chain loop -- the critical path of the whole factorisation -- spilled
+// (28 VGPRs, 100 bytes of scratch per lane).  A role is entered once per launch, so the call costs nothing.
+__device__ __attribute__((noinline)) void chain_role_inverses(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
+    const FlowArgs &g = *gp;
+    const int tid = threadIdx.x;
+    // ---- the inverses ----------------------------------------------------------------------------------------------
+    for (int c = 0; c < g.nb; c++) {
+        if (tid == 0) {
+            const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();
+        const bool ok = (*s_okp) != 0;
+        __syncthreads();
+        if (!ok) return;
+        FLOW_OPAQUE_TID(tq);      // see potrf_diag.h: nothing derived from the thread index is to live across this loop
+        diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
+        diag_block_inverses(S, Wd, tq);
+        __syncthreads();
+        if (g.inv_wt) {
+            diag_inverse<true>(S, Wd, g.invd + (long)c * 16384, 0, tq);      // write-through
+            drain_stores();
+            __syncthreads();      // every wave's part has landed; and S may be loaded again
+            if (tid == 64) {
+                flow_st(g.done + (long)c * g.fs + c, 1);
+                flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
+            }
+        } else {
+            diag_inverse<false>(S, Wd, g.invd + (long)c * 16384, 0, tq);
+            drain_stores();
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                drain_stores();
+                flow_st(g.done + (long)c * g.fs + c, 1);
+                flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
+            }
+            __syncthreads();
+        }
+    }
+    return;
+}
+__device__ __attribute__((noinline)) void chain_role_second(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
+    const FlowArgs &g = *gp;
+    const int tid = threadIdx.x;
+    // ---- the second subdiagonal: workgroup 2 finishes tile (c+2, c) by the same block forward substitution as the chain
+    //      (from L_cc itself: it does not wait for the inverse) and subtracts it from tile (c+2, c+1), the tile the chain
+    //      workgroup needs next -- the path that used to take three tile workgroups in a row (inverse -> product with
+    //      the inverse -> update) and set the period of the chain.
+    for (int c = 0; c + 2 < g.nb; c++) {
+        if (tid == 0) {
+            const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();
+        if ((*s_okp) == 0) return;
+        __syncthreads();
+        d4_t y[8][2];
+        {
+            FLOW_OPAQUE_TID(tq);
+            diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
+            diag_block_inverses(S, Wd, tq);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c, c + 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();       // also: Wd is complete
+        if ((*s_okp) == 0) return;
+        __syncthreads();
+        double *T2 = g.L + (long)(c + 2) * 128 * g.ld + (long)c * 128;      // tile (c+2, c)
+        {
+            FLOW_OPAQUE_TID(tq);
+            chain_tile_load(T2, g.ld, y, tq);
+            chain_tile_solve(y, S, Wd, tq);
+            chain_tile_store(T2, g.ld, y, tq);
+        }
+        drain_stores();
+        __syncthreads();       // L[c+2][c] has landed; every wave has read L_cc for the last time
+        if (tid == 64) flow_st(g.done + (long)(c + 2) * g.fs + c, 1);
+        if (!g.second_update) continue;
+        if (tid == 0) {
+            bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c + 1, c + 1, g.ctrl, g.timeout, nullptr);
+            r = r && flow_spin(g.done + (long)(c + 1) * g.fs + c, 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();
+        if ((*s_okp) == 0) return;
+        __syncthreads();
+        {
+            FLOW_OPAQUE_TID(tq);
+            d4_t t[8][2];
+            chain_tile_to_lds(g.L + (long)(c + 1) * 128 * g.ld + (long)c * 128, g.ld, S, tq);      // L[c+1][c]
+            chain_tile_load(T2 + 128, g.ld, t, tq);                                                 // tile (c+2, c+1)
+            __syncthreads();
+            chain_tile_update(t, y, S, tq);
+            chain_tile_store(T2 + 128, g.ld, t, tq);
+        }
+        drain_stores();
+        __syncthreads();
+        if (tid == 64) flow_st(g.applied + (long)(c + 2) * g.fs + c + 1, c + 2);
+    }
+    return;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Chain form of the diagonal kernel: TWO workgroups, each on a reserved CU of its own.
 //
@@ -734,113 +853,10 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
         // ... then: resident, the tile kernel may come
         if (g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if (blockIdx.x == 1) {
-        // ---- the inverses ----------------------------------------------------------------------------------------------
-        for (int c = 0; c < g.nb; c++) {
-            if (tid == 0) {
-                const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                drain_stores();
-                s_ok = r ? 1 : 0;
-            }
-            __syncthreads();
-            const bool ok = s_ok != 0;
-            __syncthreads();
-            if (!ok) return;
-            FLOW_OPAQUE_TID(tq);      // see potrf_diag.h: nothing derived from the thread index is to live across this loop
-            diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
-            diag_block_inverses(S, Wd, tq);
-            __syncthreads();
-            if (g.inv_wt) {
-                diag_inverse<true>(S, Wd, g.invd + (long)c * 16384, 0, tq);      // write-through
-                drain_stores();
-                __syncthreads();      // every wave's part has landed; and S may be loaded again
-                if (tid == 64) {
-                    flow_st(g.done + (long)c * g.fs + c, 1);
-                    flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
-                }
-            } else {
-                diag_inverse<false>(S, Wd, g.invd + (long)c * 16384, 0, tq);
-                drain_stores();
-                __syncthreads();
-                if (tid == 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    drain_stores();
-                    flow_st(g.done + (long)c * g.fs + c, 1);
-                    flow_st(g.ctrl + FLOW_DIAG_NEXT, c + 1);
-                }
-                __syncthreads();
-            }
-        }
-        return;
-    }
-    if (blockIdx.x == 2) {
-        // ---- the second subdiagonal: workgroup 2 finishes tile (c+2, c) by the same block forward substitution as the chain
-        //      (from L_cc itself: it does not wait for the inverse) and subtracts it from tile (c+2, c+1), the tile the chain
-        //      workgroup needs next -- the path that used to take three tile workgroups in a row (inverse -> product with
-        //      the inverse -> update) and set the period of the chain.
-        for (int c = 0; c + 2 < g.nb; c++) {
-            if (tid == 0) {
-                const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                drain_stores();
-                s_ok = r ? 1 : 0;
-            }
-            __syncthreads();
-            if (s_ok == 0) return;
-            __syncthreads();
-            d4_t y[8][2];
-            {
-                FLOW_OPAQUE_TID(tq);
-                diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
-                diag_block_inverses(S, Wd, tq);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                const bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c, c + 1, g.ctrl, g.timeout, nullptr);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                drain_stores();
-                s_ok = r ? 1 : 0;
-            }
-            __syncthreads();       // also: Wd is complete
-            if (s_ok == 0) return;
-            __syncthreads();
-            double *T2 = g.L + (long)(c + 2) * 128 * g.ld + (long)c * 128;      // tile (c+2, c)
-            {
-                FLOW_OPAQUE_TID(tq);
-                chain_tile_load(T2, g.ld, y, tq);
-                chain_tile_solve(y, S, Wd, tq);
-                chain_tile_store(T2, g.ld, y, tq);
-            }
-            drain_stores();
-            __syncthreads();       // L[c+2][c] has landed; every wave has read L_cc for the last time
-            if (tid == 64) flow_st(g.done + (long)(c + 2) * g.fs + c, 1);
-            if (!g.second_update) continue;
-            if (tid == 0) {
-                bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c + 1, c + 1, g.ctrl, g.timeout, nullptr);
-                r = r && flow_spin(g.done + (long)(c + 1) * g.fs + c, 1, g.ctrl, g.timeout, nullptr);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                drain_stores();
-                s_ok = r ? 1 : 0;
-            }
-            __syncthreads();
-            if (s_ok == 0) return;
-            __syncthreads();
-            {
-                FLOW_OPAQUE_TID(tq);
-                d4_t t[8][2];
-                chain_tile_to_lds(g.L + (long)(c + 1) * 128 * g.ld + (long)c * 128, g.ld, S, tq);      // L[c+1][c]
-                chain_tile_load(T2 + 128, g.ld, t, tq);                                                 // tile (c+2, c+1)
-                __syncthreads();
-                chain_tile_update(t, y, S, tq);
-                chain_tile_store(T2 + 128, g.ld, t, tq);
-            }
-            drain_stores();
-            __syncthreads();
-            if (tid == 64) flow_st(g.applied + (long)(c + 2) * g.fs + c + 1, c + 2);
-        }
-        return;
-    }
+    // (the roles read the arguments where the dispatch packet put them: taking the address of `g` would copy the struct to the stack
+    // and send every later g.field of the chain loop through scratch)
+    if (blockIdx.x == 1) { chain_role_inverses((const FlowArgs *)__builtin_amdgcn_kernarg_segment_ptr(), S, Wd, &s_ok); return; }
+    if (blockIdx.x == 2) { chain_role_second((const FlowArgs *)__builtin_amdgcn_kernarg_segment_ptr(), S, Wd, &s_ok); return; }
     // ---- the chain -------------------------------------------------------------------------------------------------
     if (tid == 0) {
         const bool r = flow_spin(g.applied, 1, g.ctrl, g.timeout, nullptr);      // tile (0, 0): scaled, in L
@@ -972,10 +988,14 @@ hipError_t DenseSolver::flow_init() {
     // chain form unless kernels cannot run side by side (one-kernel form, diagonal blocks inline) or it is switched off
     flow_one_kernel = !flow_kernels_overlap();
     flow_chain = !flow_one_kernel && !(getenv("JAICOV_FLOW_CHAIN") && atoi(getenv("JAICOV_FLOW_CHAIN")) == 0);
+    // the chain workgroups take a CU each (150 KB of LDS): with fewer reserved CUs than chain workgroups (JAICOV_RESERVED_CUS=1)
+    // the second one could only start when the first has left, and the residency handshake of potrf_flow would never complete --
+    // the single-workgroup companion (potrf_diag_chain_kernel) fits on one CU
+    if (flow_chain && reserved_cus < 2) flow_chain = false;
     // third chain workgroup for the second subdiagonal: 0 = none (default: measured equal, 22.4 ms at order 15 104, because the
     // tiles it needs are themselves late by the same path one diagonal further out), 1 = it finishes tile (c+2, c), 2 = and
     // subtracts it from tile (c+2, c+1)
-    flow_second = flow_chain && getenv("JAICOV_FLOW_SECOND") ? std::min(std::max(atoi(getenv("JAICOV_FLOW_SECOND")), 0), 2) : 0;
+    flow_second = flow_chain && reserved_cus >= 3 && getenv("JAICOV_FLOW_SECOND") ? std::min(std::max(atoi(getenv("JAICOV_FLOW_SECOND")), 0), 2) : 0;
     const std::vector<int4> tasks = flow_schedule(nb, row_blocks, getenv("JAICOV_FLOW_W") ? atoi(getenv("JAICOV_FLOW_W")) : 1, flow_chain, flow_second);
     flow_tasks = (int)tasks.size();
     flow_task_host = tasks;
@@ -1059,7 +1079,15 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.crit_prio = getenv("JAICOV_FLOW_PRIO") ? atoi(getenv("JAICOV_FLOW_PRIO")) : 1;
     g.second_update = flow_second >= 2 ? 1 : 0;
     g.second_wg = flow_second ? 1 : 0;
-    g.keep = flow_chain && !getenv("JAICOV_FLOW_KEEP_ALL") ? 8 * (flow_grid / 8 - 8) : 0;
+    // "the last eight workgroups of every XCD" presumes the grid the observation was made with: two workgroups per CU dealt
+    // round-robin to eight XCDs.  Any other grid (JAICOV_FLOW_GRID) keeps every workgroup: the rule would pick the wrong ones.
+    {
+        int cus = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        const bool standard_grid = cus > 0 && cus % 8 == 0 && flow_grid == 2 * cus && flow_grid / 8 > 8;
+        g.keep = flow_chain && standard_grid && !getenv("JAICOV_FLOW_KEEP_ALL") ? 8 * (flow_grid / 8 - 8) : 0;
+    }
     g.inv_wt = getenv("JAICOV_FLOW_INV_WT") ? atoi(getenv("JAICOV_FLOW_INV_WT")) : 1;
     g.crit_span = getenv("JAICOV_FLOW_PRIO_SPAN") ? atoi(getenv("JAICOV_FLOW_PRIO_SPAN")) : (flow_chain ? 2 : 1);
     g.alive = flow_alive;
@@ -1102,8 +1130,21 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
         while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq ||
                (flow_chain && (__atomic_load_n(flow_alive + 1, __ATOMIC_ACQUIRE) != g.seq ||
                                (flow_second && __atomic_load_n(flow_alive + 2, __ATOMIC_ACQUIRE) != g.seq)))) {
-            if ((++spins & 1023) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 30.0)
-                return hipErrorLaunchTimeOut;
+            if ((++spins & 1023) == 0) {
+                const double waited_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+                if (waited_s > 30.0) {
+                    // the companion never became resident: tell it to leave (its waits watch the abort word), wait for it, and join
+                    // the streams again, so that a later factorisation cannot clear the flags under a kernel that still runs
+                    const int two = 2;
+                    (void)hipMemcpyAsync(flow_flags + FLOW_ABORT, &two, sizeof(int), hipMemcpyHostToDevice, pstream ? pstream : stream);
+                    (void)hipStreamSynchronize(pstream ? pstream : stream);
+                    (void)hipStreamSynchronize(dstream);
+                    (void)hipEventRecord(flow_e1, dstream);
+                    (void)hipStreamWaitEvent(stream, flow_e1, 0);
+                    return hipErrorLaunchTimeOut;
+                }
+                if (waited_s > 2e-4) std::this_thread::yield();      // the companion waits for earlier work on `stream`: do not burn the core meanwhile
+            }
         }
     }
     if (profile) HIPCHK(hipEventRecord(flow_t0, stream));

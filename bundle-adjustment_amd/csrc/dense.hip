@@ -56,8 +56,11 @@ __device__ __forceinline__ void bs_row(const double *p, double (&v)[NR]) {
 template <int NR>
 __global__ __launch_bounds__(256) void backsolve_chain_kernel(const double *__restrict__ L, long ld,
                                                               const double *__restrict__ invd, const double *__restrict__ Z,
-                                                              long zs, double *X, long xs, int nb, int nrhs) {
+                                                              long zs, double *X, long xs, int nb, int nrhs, const int *abort_word) {
     __shared__ __attribute__((aligned(32))) double xj[2][128][NR];     // x_j (then v_k), [row][rhs]
+    // behind an abandoned dataflow factorisation (cholflow.hip: abort word set) the factor is garbage and the host will repeat
+    // everything: leave at once (X keeps its "not published" pattern, which reads as NaN)
+    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     __shared__ __attribute__((aligned(32))) double red[4][128][NR];    // partial sums
     const int tid = threadIdx.x;
     const int k = nb - 1 - (int)blockIdx.x;
@@ -632,10 +635,11 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     if (!aug || nrhs < 1 || nrhs > DENSE_MAX_RHS) return hipErrorInvalidValue;
     const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nrhs * xs * sizeof(double), stream));   // "not yet published"
-    if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
-    else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
-    else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
-    else hipLaunchKernelGGL(backsolve_chain_kernel<8>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs);
+    const int *ab = flow_ready ? flow_flags + 1 : nullptr;      // cholflow.hip FLOW_ABORT
+    if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
+    else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
+    else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
+    else hipLaunchKernelGGL(backsolve_chain_kernel<8>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     return hipGetLastError();
 }
 
@@ -646,7 +650,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
     HIPCHK(hipMemsetAsync(tmp, 0xFF, (size_t)nfact * sizeof(double), stream));
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nfact * sizeof(double), stream));
     hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
-    hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, tmp, (long)nfact, X, (long)nfact, nb, 1);
+    hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, tmp, (long)nfact, X, (long)nfact, nb, 1, (const int *)nullptr);
     return hipGetLastError();
 }
 

@@ -313,14 +313,24 @@ static int check_device(std::string &err) {
 static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_D, int m, double *d_out,
                              const int32_t *d_perm = nullptr) {
     const int mp = ds.n;
-    hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp, d_perm);
-    HIPE(e, ds.potrf());
+    int info = 0;
+    for (int attempt = 0;; attempt++) {      // an abandoned dataflow factorisation (-9; orders >= 24 block columns) is repeated: d_D is untouched
+        hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp, d_perm);
+        HIPE(e, ds.potrf());
+        info = ds.fetch_info();
+        if (info == -9 && attempt < 2) {
+            ++e->flow_retries;
+            fprintf(stderr, "jaicov: factorisation of a dispersion matrix abandoned on the device (a wait ran into its time limit); repeating it (%d)\n", attempt + 1);
+            continue;
+        }
+        break;
+    }
+    if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation of a dispersion matrix did not complete on the device (code " + std::to_string(info) + ")");
+    if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)");
     HIPE(e, ds.trtri());
     HIPE(e, ds.lauum());
     hipLaunchKernelGGL(store_inv_kernel, dim3((m + 255) / 256, m), dim3(256), 0, e->stream, ds.Q, ds.ld, m, d_out);
-    const int info = ds.fetch_info();
-    if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation of a dispersion matrix did not complete on the device (code " + std::to_string(info) + ")");
-    if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)");
+    HIPE(e, hipStreamSynchronize(e->stream));
     return JAICOV_OK;
 }
 
@@ -1379,6 +1389,14 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     return JAICOV_OK;
 }
 
+extern "C" int jaicov_neq_eo_step_buffer(jaicov_engine *e, void **device_ptr, size_t *count) {
+    if (!e || !device_ptr || !count) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state != jaicov_engine::ST_SOLVED || !e->schur_active || !e->d_xE) FAIL(e, JAICOV_ERR_BAD_STATE, "no pre-eliminated exterior orientations: solve a reduced system first");
+    *device_ptr = e->d_xE;
+    *count = (size_t)6 * e->p.n_images;
+    return JAICOV_OK;
+}
+
 extern "C" int jaicov_neq_omega(jaicov_engine *e, double sigma2, const double *dx, double *omega) {
     if (!e || !dx || !omega) return JAICOV_ERR_BAD_ARGUMENT;
     if (e->state == jaicov_engine::ST_NEW) FAIL(e, JAICOV_ERR_BAD_STATE, "set_parameters first");
@@ -1528,6 +1546,13 @@ extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t 
     if (!e || !stats || n < 3) return JAICOV_ERR_BAD_ARGUMENT;
     stats[0] = e->solver.stat_launches; stats[1] = e->solver.stat_ms; stats[2] = e->solver.stat_flops;
     if (n >= 6) { stats[3] = e->dm_stat_passes; stats[4] = e->dm_stat_ms; stats[5] = e->dm_stat_flops; }
+    if (n >= 10) {   // health of the dataflow factorisation since create (never reset): see jaicov_neq.h
+        stats[6] = (double)e->flow_retries;
+        stats[7] = (double)(e->solver.flow_stale_events + e->solverS.flow_stale_events);
+        stats[8] = (double)(e->solver.flow_stale_confirmed + e->solverS.flow_stale_confirmed);
+        stats[9] = (double)(e->solver.flow_rescued + e->solverS.flow_rescued);
+    }
+    if (n >= 11) stats[10] = e->last_refine_correction;
     if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = e->dm_stat_passes = e->dm_stat_ms = e->dm_stat_flops = 0.0;
     return JAICOV_OK;
 }

@@ -102,9 +102,16 @@ def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
     dx = eng.solve(invert)
     e0 = eng.reduced_order()
     if e0 < eng.U and dist.get_world_size() > 1:
-        t = torch.from_numpy(dx[e0:].copy()).to(device)
-        dist.all_reduce(t)
-        dx[e0:] = t.cpu().numpy()
+        if device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl":
+            # the EO steps stay where the back-substitution left them: all-reduce the engine's device array in place, one copy back
+            ptr, cnt = eng.eo_step_buffer()
+            t = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
+            dist.all_reduce(t)
+            dx[e0:] = t.cpu().numpy()[:eng.U - e0]
+        else:                                           # gloo rehearsal: host tensors
+            t = torch.from_numpy(dx[e0:].copy())
+            dist.all_reduce(t)
+            dx[e0:] = t.numpy()
     return dx
 
 

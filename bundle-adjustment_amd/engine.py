@@ -27,7 +27,7 @@ EXPORTS = [
     "jaicov_neq_solve", "jaicov_neq_omega", "jaicov_neq_update", "jaicov_neq_get_normal", "jaicov_neq_get_cofactor",
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_dispersion_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
     "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats", "jaicov_neq_cancel",
-    "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm",
+    "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm", "jaicov_neq_eo_step_buffer",
 ]
 
 KROW = 32  # 12 + JAICOV_MAX_DIST_PER_CAMERA
@@ -102,6 +102,7 @@ def load_library():
     L.jaicov_neq_reduce_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.jaicov_neq_reduce_buffer_async.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.jaicov_neq_solve.argtypes = [vp, C.c_int, _pd]
+    L.jaicov_neq_eo_step_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.jaicov_neq_omega.argtypes = [vp, C.c_double, _pd, _pd]
     L.jaicov_neq_update.argtypes = [vp, _pd, _pd]
     L.jaicov_neq_get_normal.argtypes = [vp, _pd, C.c_size_t, _pd, C.c_size_t]
@@ -210,6 +211,12 @@ class Engine:
         self._chk(self.L.jaicov_neq_reduce_buffer_async(self._h, C.byref(ptr), C.byref(cnt), C.byref(st)))
         return ptr.value, cnt.value, st.value
 
+    def eo_step_buffer(self):
+        """(device pointer, count) of the EO steps this engine back-substituted in the last solve (6 per image, zeros elsewhere)."""
+        ptr = C.c_void_p(); cnt = C.c_size_t()
+        self._chk(self.L.jaicov_neq_eo_step_buffer(self._h, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value
+
     def solve(self, invert=False):
         dx = np.zeros(max(self.U, 1))
         self._chk(self.L.jaicov_neq_solve(self._h, int(invert), _p(dx)))
@@ -269,9 +276,11 @@ class Engine:
         self._chk(self.L.jaicov_neq_set_profiling(self._h, int(on)))
 
     def kernel_stats(self, reset=False):
-        st = np.zeros(6)
-        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 6, int(reset)))
-        return {"launches": st[0], "ms": st[1], "flops": st[2], "dense_passes": st[3], "dense_gemm_ms": st[4], "dense_flops": st[5]}
+        st = np.zeros(11)
+        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 11, int(reset)))
+        return {"launches": st[0], "ms": st[1], "flops": st[2], "dense_passes": st[3], "dense_gemm_ms": st[4], "dense_flops": st[5],
+                "flow_retries": int(st[6]), "flow_stale_events": int(st[7]), "flow_stale_confirmed": int(st[8]),
+                "flow_rescued": int(st[9]), "last_refinement_correction": float(st[10])}
 
     def cancel(self):
         """``BundleAdjustment.interrupt()`` (BundleAdjustment.java:1455): the running / next ``estimate`` ends with state -1."""

@@ -246,6 +246,12 @@ int jaicov_neq_reduce_buffer_async(jaicov_engine *e, void **device_ptr, size_t *
  * invert = JAICOV_INVERT_*: != NONE keeps Qxx on the device (BA:274).                                     */
 int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out);
 
+/* After a solve on a system whose exterior orientations were pre-eliminated (jaicov_neq_reduced_order() < U): the DEVICE array of
+ * the EO steps this engine back-substituted, 6 doubles per image in image order (*count = 6 * images), zero for the images of
+ * other ranks.  dx_out[reduced_order + i] of the solve holds the same numbers.  A multi-GPU host sums the array over the ranks in
+ * place (ncclAllReduce) and copies it into the tail of dx, instead of sending the host copy back to the device for the collective. */
+int jaicov_neq_eo_step_buffer(jaicov_engine *e, void **device_ptr, size_t *count);
+
 /* replaces BA.getOmega(dx) (BA:472-491): sum over groups of (w - A dx)' P (w - A dx) at the CURRENT
  * (pre-update) parameters.                                                                               */
 int jaicov_neq_omega(jaicov_engine *e, double sigma2apriori, const double *dx, double *omega);
@@ -308,7 +314,12 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
  * every such launch is bracketed by HIP events on the engine stream.  stats: [0] launches, [1] summed device ms,
  * [2] summed algorithmic flops (rows*(rows+1)*K per lower-triangular update), since the last reset.  With n >= 6 and
  * assembly_mode = 1: [3] passes, [4] summed device ms of the two J'WJ GEMM launches per batch of images, [5] summed
- * algorithmic flops of SURVEY 8(d)'s dense-group row, sum_g 2 m^2 (k+1) + m (k+1)(k+2).                              */
+ * algorithmic flops of SURVEY 8(d)'s dense-group row, sum_g 2 m^2 (k+1) + m (k+1)(k+2).
+ * With n >= 10, health counters of the dataflow factorisation since jaicov_neq_create (not reset): [6] factorisations that were
+ * abandoned on the device (a bounded wait ran out) and repeated, [7] flags that only the slow-path poll found, [8] of those the
+ * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == [9] == 0;
+ * bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
+ * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).                                     */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset);
 

@@ -15,6 +15,7 @@
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include "jaicov_neq.h"
 
@@ -189,33 +190,48 @@ JNIEXPORT jint JNICALL NAT(prepareInverse)(JNIEnv *e, jclass k, jlong h, jint in
 JNIEXPORT jint JNICALL NAT(reducedOrder)(JNIEnv *e, jclass k, jlong h) { (void)e; (void)k; return jaicov_neq_reduced_order(ENG(h)); }
 JNIEXPORT jint JNICALL NAT(cofactorOrder)(JNIEnv *e, jclass k, jlong h) { (void)e; (void)k; return jaicov_neq_cofactor_order(ENG(h)); }
 
+/* dx arrays must hold exactly U doubles: U (U + 1) / 2 == jaicov_neq_packed_length().  Checked before anything is read. */
+static int has_u_entries(JNIEnv *e, jlong h, jdoubleArray dx) {
+    const size_t n = (size_t)(*e)->GetArrayLength(e, dx);
+    return n * (n + 1) / 2 == jaicov_neq_packed_length(ENG(h));
+}
+/* The calls below block on the device (a factorisation, its possible repeat, the inverse: up to seconds).  A critical region would
+ * stall every garbage collection of the JVM for that long, so the vectors travel through a malloc'd copy (U doubles: 0.14 MB at
+ * config 4) with Get/SetDoubleArrayRegion instead of GetPrimitiveArrayCritical. */
 JNIEXPORT jint JNICALL NAT(solve)(JNIEnv *e, jclass k, jlong h, jint invert, jdoubleArray dx) {   /* invert = JAICOV_INVERT_* = MatrixInversion (BA:65-70) */
     (void)k;
-    if ((size_t)(*e)->GetArrayLength(e, dx) * ((size_t)(*e)->GetArrayLength(e, dx) + 1) / 2 != jaicov_neq_packed_length(ENG(h)))
-        return JAICOV_ERR_BAD_ARGUMENT;                  /* dx must have U entries */
-    double *p = (double *)(*e)->GetPrimitiveArrayCritical(e, dx, NULL);
+    if (!has_u_entries(e, h, dx)) return JAICOV_ERR_BAD_ARGUMENT;
+    const jsize n = (*e)->GetArrayLength(e, dx);
+    double *p = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     if (!p) return JAICOV_ERR_OUT_OF_MEMORY;
     int rc = jaicov_neq_solve(ENG(h), (int)invert, p);
-    (*e)->ReleasePrimitiveArrayCritical(e, dx, p, 0);
+    if (rc == JAICOV_OK) (*e)->SetDoubleArrayRegion(e, dx, 0, n, p);
+    free(p);
     return rc;
 }
 JNIEXPORT jint JNICALL NAT(omega)(JNIEnv *e, jclass k, jlong h, jdouble s2, jdoubleArray dx, jdoubleArray out) {
     (void)k;
     double om = 0.0;
-    double *p = (double *)(*e)->GetPrimitiveArrayCritical(e, dx, NULL);
+    if (!has_u_entries(e, h, dx) || (*e)->GetArrayLength(e, out) < 1) return JAICOV_ERR_BAD_ARGUMENT;
+    const jsize n = (*e)->GetArrayLength(e, dx);
+    double *p = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     if (!p) return JAICOV_ERR_OUT_OF_MEMORY;
+    (*e)->GetDoubleArrayRegion(e, dx, 0, n, p);
     int rc = jaicov_neq_omega(ENG(h), s2, p, &om);
-    (*e)->ReleasePrimitiveArrayCritical(e, dx, p, JNI_ABORT);
+    free(p);
     (*e)->SetDoubleArrayRegion(e, out, 0, 1, &om);
     return rc;
 }
 JNIEXPORT jint JNICALL NAT(update)(JNIEnv *e, jclass k, jlong h, jdoubleArray dx, jdoubleArray mx) {
     (void)k;
     double m = 0.0;
-    double *p = (double *)(*e)->GetPrimitiveArrayCritical(e, dx, NULL);
+    if (!has_u_entries(e, h, dx) || (*e)->GetArrayLength(e, mx) < 1) return JAICOV_ERR_BAD_ARGUMENT;
+    const jsize n = (*e)->GetArrayLength(e, dx);
+    double *p = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
     if (!p) return JAICOV_ERR_OUT_OF_MEMORY;
+    (*e)->GetDoubleArrayRegion(e, dx, 0, n, p);
     int rc = jaicov_neq_update(ENG(h), p, &m);
-    (*e)->ReleasePrimitiveArrayCritical(e, dx, p, JNI_ABORT);
+    free(p);
     (*e)->SetDoubleArrayRegion(e, mx, 0, 1, &m);
     return rc;
 }

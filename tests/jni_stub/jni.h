@@ -37,6 +37,7 @@ struct JNINativeInterface_ {
     void (*ReleaseLongArrayElements)(JNIEnv *, jlongArray, jlong *, jint);
     void (*ReleaseByteArrayElements)(JNIEnv *, jbyteArray, jbyte *, jint);
     void (*ReleaseDoubleArrayElements)(JNIEnv *, jdoubleArray, jdouble *, jint);
+    void (*GetDoubleArrayRegion)(JNIEnv *, jdoubleArray, jsize, jsize, jdouble *);
     void (*SetDoubleArrayRegion)(JNIEnv *, jdoubleArray, jsize, jsize, const jdouble *);
     void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);
     void *(*GetPrimitiveArrayCritical)(JNIEnv *, jarray, jboolean *);
