@@ -216,6 +216,12 @@ def main():
         elapsed = float(tt.item())
     ks = eng.kernel_stats()
     eng.set_profiling(False)
+    # health of the dataflow factorisation on EVERY rank (a repeated factorisation costs >= 0.25 s: a line measured with one is flagged)
+    flow = [ks["flow_retries"], ks["flow_stale_events"], ks["flow_stale_confirmed"], ks["flow_rescued"]]
+    if use_dist:
+        ft = torch.tensor(flow, dtype=torch.float64, device="cuda")
+        dist.all_reduce(ft)
+        flow = [int(v) for v in ft.tolist()]
 
     out = None
     if rank == 0:
@@ -230,6 +236,10 @@ def main():
                        "parallelism": f"images sharded over {world} rank(s), packed N all-reduced, replicated solve",
                        "rccl_ranks": (dist.get_world_size() if use_dist else 0)},
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items()},
+            "flow": {"retries": flow[0], "stale_events": flow[1], "stale_confirmed": flow[2], "rescued": flow[3],
+                     "ok": flow[0] == 0, "note": "summed over ranks since engine creation; retries > 0 = a factorisation was abandoned and repeated inside the timed region or the warm-up"},
+            "refinement": {"steps_per_solve": int(os.environ.get("JAICOV_REFINE", "1")), "last_correction_rel": ks["last_refinement_correction"],
+                           "note": "iterative refinement of dx (two-fold-precision residual + forward/backward substitution), inside the timed step (stage 'solve')"},
             "roofline": {"kernel": ("gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update of the stream-scheduled factorisation, fp64 MFMA 16x16x4)"
                                     if os.environ.get("JAICOV_POTRF_LEGACY") else
                                     "chol_tile_kernel<1, false> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
@@ -266,8 +276,41 @@ def main():
                 L.jaicov_debug_mfma_peak(2048, iters, C.byref(ms_), C.byref(tf_))
                 meas.append(tf_.value)
             out["roofline"]["peak_measured"] = {"constant_operands": meas[0], "random_operands": meas[1], "unit": "TFLOP/s"}
+            if meas[1] > 0:
+                out["roofline"]["frac_of_measured_peak"] = achieved / meas[1]     # against what the chip sustains on random operands (power-limited)
         except Exception:
             pass
+        # registers / spills / scratch of the kernels of the LM pass, from the resource remarks of the build that produced the loaded
+        # library (csrc/kernel_resources.json, written by the Makefile)
+        try:
+            kr = json.load(open(os.path.join(ROOT, "bundle-adjustment_amd", "csrc", "kernel_resources.json")))
+            lm = ("chol_tile_kernel<1, false>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false>", "blk_T_mfma_kernel", "blk_elim_kernel",
+                  "blk_tfix_kernel", "blk_cc", "blk_pc_gather", "rows_kernel", "backsolve_chain_kernel<1>", "forwardsolve_chain_kernel",
+                  "symv_dd_tile_kernel", "symv_dd_reduce_kernel", "blk_backsub_kernel", "damp_and_precond_kernel")
+            tab = {}
+            for name, v in kr.items():
+                short = name.replace("jaicov::", "").replace("void ", "")
+                if any(short.startswith(k) for k in lm):
+                    tab[short.split("(")[0]] = {k: v.get(k, 0) for k in ("vgprs", "agprs", "vgpr_spills", "scratch_bytes_per_lane", "lds_bytes", "occupancy")}
+            out["kernel_resources"] = {"source": "csrc/kernel_resources.json (hipcc -Rpass-analysis=kernel-resource-usage of the shipped build)",
+                                       "kernels_with_vgpr_spills": sorted(k for k, v in tab.items() if v["vgpr_spills"]),
+                                       "lm_pass": tab,
+                                       "note": "potrf_chain_kernel's scratch is the frame of its two companion roles (real calls, entered once per launch); the chain loop has no scratch access"}
+        except Exception:
+            pass
+        if world >= 1:
+            # what the replicated solve lets N GPUs do: T(N) = assembly / N + R(N) + the rest; R = pack + ring
+            # all-reduce of the packed reduced system + unpack.  A model, printed so that a scaling run can be read against it.
+            st = out["stage_ms_per_step"]
+            asm = st.get("rows", 0.0) + st.get("assembly", 0.0)
+            rest = out["ms_per_step"] - asm if world == 1 else None
+            gb = 8e-9 * (eng.reduced_order() * (eng.reduced_order() + 1) / 2 + 2 * eng.reduced_order())
+            busbw = {2: 120.0, 4: 250.0, 8: 320.0}      # GB/s, assumed: one xGMI link (153 peak) at N = 2, rings over 3 / 7 links beyond
+            if rest is not None:
+                out["expected_scaling"] = {"model": "T(N) = (rows + assembly) / N + 0.72 ms pack/unpack + 2 (N-1)/N x bytes / busbw(N) + everything else (replicated)",
+                                           "reduce_buffer_GB": gb, "assumed_busbw_GBps": busbw,
+                                           "ms_per_step": {"1": out["ms_per_step"], **{str(n): asm / n + 0.72 + 1e3 * 2 * (n - 1) / n * gb / busbw[n] + rest for n in (2, 4, 8)}},
+                                           "note": "N > 1 is expected to be SLOWER than N = 1 while the solve is replicated (the shardable assembly is ~12 % of the pass)"}
         # HBM bytes per launch come from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need a pass each and cannot be collected
         # inside this run): scripts/round_profile.sh regenerates profiles/pmc_traffic.json; the line says which file it quotes.
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
