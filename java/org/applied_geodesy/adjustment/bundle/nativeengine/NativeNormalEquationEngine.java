@@ -40,7 +40,11 @@ public final class NativeNormalEquationEngine implements AutoCloseable {
 	public long[] reduceBuffer() { long[] r = new long[2]; check(reduceBuffer(handle, r)); return r; }
 	/** NES.applyPrecondition + MathExtension.solve(N, n, invert) + reverse preconditioning (BA:238,270-297) */
 	public void solve(int invert, double[] dx) { check(solve(handle, invert, dx)); }
-	/** MatrixInversion -> JAICOV_INVERT_*: NONE 0, FULL 1, REDUCED and PRE_ELIMINATION 2 (BA:65-70, 261-271) */
+	/**
+	 * MatrixInversion -> JAICOV_INVERT_*: NONE 0, FULL 1, REDUCED and PRE_ELIMINATION 2 (BA:65-70, 261-271).  3 = FULL_EXPANDED: the
+	 * same matrix as FULL, expanded from the inverse of the EO-reduced system (faster and more accurate where the engine can
+	 * pre-eliminate; served as FULL where it cannot) -- what the patched estimateModel() passes for MatrixInversion.FULL.
+	 */
 	public static int invertMode(Enum<?> matrixInversion) {
 		switch (matrixInversion.name()) { case "NONE": return 0; case "FULL": return 1; default: return 2; }
 	}

@@ -100,3 +100,75 @@ def test_shim_compiles_against_a_minimal_jni_header():
     src = open(SHIM).read()
     assert not re.search(r"ReleasePrimitiveArrayCritical\(e, [^,]+, NULL", src)
     assert "rc != JAICOV_OK" in src and "throw_status(e, rc, msg)" in src
+
+
+# ---- the Java side of the flattening (java/.../ProblemFlattener.java + java/patch/*.patch), checked as text ---------------------
+FLAT = os.path.join(ROOT, "java", "org", "applied_geodesy", "adjustment", "bundle", "nativeengine", "ProblemFlattener.java")
+PATCH = os.path.join(ROOT, "java", "patch")
+
+
+def _description_fields():
+    java = open(JAVA).read()
+    body = java[java.index("class ProblemDescription"):]
+    body = body[:body.index("}")]
+    fields = {}
+    for typ, names in re.findall(r"public ([\w\[\]]+) ([\w, ]+);", body):
+        for n in names.split(","):
+            fields[n.strip()] = typ
+    return fields
+
+
+def test_flattener_fills_every_field_of_the_problem_description():
+    src = open(FLAT).read()
+    fields = _description_fields()
+    assigned = set(re.findall(r"\bd\.(\w+)\s*=[^=]", src))
+    assert assigned == set(fields), (sorted(set(fields) - assigned), sorted(assigned - set(fields)))
+    # element types: arrays are created / converted with the type the description declares
+    conv = {"int[]": ("new int[", "toIntArray("), "long[]": ("toLongArray(",), "double[]": ("new double[", "toDoubleArray(", "concat("),
+            "byte[]": ("new byte[",)}
+    for name, typ in fields.items():
+        if typ == "int":
+            continue
+        rhs = re.search(r"\bd\.%s\s*=\s*([^;]+);" % name, src).group(1)
+        assert any(rhs.strip().startswith(c) for c in conv[typ]), (name, typ, rhs)
+    # UnknownParameter.java:27: fixed = Integer.MAX_VALUE -> JAICOV_COL_FIXED (-1); unset (-1) never reaches the engine as a column
+    assert re.search(r"c == Integer\.MAX_VALUE \|\| c < 0\) \? -1 : c", src)
+    # the walk follows prepareUnknownParameters(): points, interior orientation, distortion, exterior orientation, image points,
+    # scale bars, directly observed groups -- the slot order of include/jaicov_neq.h
+    order = [src.index(k) for k in ("d.pointColumn = new", "d.interiorColumn = new", "d.distortionKind =", "d.exteriorColumn =",
+                                    "d.imagePointImage =", "d.scaleBarA = new", "d.directSlot =")]
+    assert order == sorted(order)
+    # datum bits and distortion kinds equal the header's enums
+    hdr = open(HEADER).read()
+    for name, val in re.findall(r"JAICOV_DATUM_(\w+) = (\d+)", hdr):
+        assert re.search(r"DATUM_%s = %s\b" % (name, val), src), name
+    kinds = dict(re.findall(r"JAICOV_DIST_(\w+)\s*= (\d+)", hdr))
+    for name, val in kinds.items():
+        assert re.search(r"\b%s = %s\b" % (name, val), src), name
+
+
+def test_flattener_and_patches_agree_with_the_engine_class_and_with_each_other():
+    src = open(FLAT).read()
+    eng = open(JAVA).read()
+    ba = open(os.path.join(PATCH, "BundleAdjustment.native.patch")).read()
+    img = open(os.path.join(PATCH, "Image.dispersion.patch")).read()
+    dop = open(os.path.join(PATCH, "DirectlyObservedParameterGroup.dispersion.patch")).read()
+    # API additions used by the flattener are the ones the patches add
+    assert "image.getDispersion()" in src and "public UpperSPDPackMatrix getDispersion()" in img
+    assert "public void setDispersion(UpperSPDPackMatrix dispersionMatrix)" in img
+    assert "group.getDispersionMatrix()" in src and "public UpperSPDPackMatrix getDispersionMatrix()" in dop
+    # every engine method the BundleAdjustment patch calls exists in the binding class with that name
+    public = set(re.findall(r"public (?:static )?[\w\[\]<>?]+ (\w+)\(", eng))
+    for m in set(re.findall(r"this\.engine\.(\w+)\(", ba)):
+        assert m in public, m
+    for m in set(re.findall(r"this\.flattener\.(\w+)\(", ba)):
+        assert re.search(r"public [\w\[\].]+ %s\(" % m, src), m
+    # the flatten() call passes what ProblemFlattener.flatten() takes, in that order
+    sig = re.search(r"ProblemDescription flatten\((.*?)\)\s*\{", src, flags=re.S).group(1)
+    names = [a.strip().rsplit(" ", 1)[1] for a in sig.replace("\n", " ").split(",")]
+    call = re.search(r"this\.flattener\.flatten\((.*?)\);", ba, flags=re.S).group(1)
+    passed = [a.strip().replace("this.", "") for a in call.replace("\n", " ").replace("+", "").split(",")]
+    assert names == passed, (names, passed)
+    # MatrixInversion.FULL is run as JAICOV_INVERT_FULL_EXPANDED (3), like jaicov_neq_estimate and the C++ host do
+    hdr = open(HEADER).read()
+    assert "#define JAICOV_INVERT_FULL_EXPANDED 3" in hdr and "MatrixInversion.FULL ? 3" in ba
