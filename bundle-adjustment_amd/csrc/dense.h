@@ -34,6 +34,8 @@ struct DenseSolver {
     std::map<int, std::pair<int2 *, int>> tile_maps;   // XCD-aware tile order of the trailing update, by tile rows
     bool xcd_maps = true;
     int2 *tile_map_store = nullptr;
+    std::map<long, int2 *> trtri_maps;   // tile orders of the triangular inverse's products, longest k-range first (dense.hip)
+    const int2 *trtri_tile_order(int tm, int tn, int kind);
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse

@@ -364,6 +364,8 @@ void DenseSolver::release() {
     hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q);
     hipFree(tile_map_store);
     tile_map_store = nullptr;
+    for (auto &kv : trtri_maps) hipFree(kv.second);
+    trtri_maps.clear();
     tile_maps.clear();
     for (auto ev : prof_ev) hipEventDestroy(ev);
     prof_ev.clear();
@@ -658,9 +660,34 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
 // every pair [lo, lo+h) | [lo+h, lo+2h) is merged independently:  W21 = -W22 (L21 W11).  All full pairs of a level
 // have the same shape and a constant address stride, so a level is two batched launches (product T = L21 W11 into the
 // W21-position of Q, which is free until lauum() fills it; then W21 = -W22 T); a ragged last pair gets its own two.
+// Tile orders of the two products of a merge, longest k-range first (the tiles of these launches do triangular work: in
+// T = L21 W11 the k-range of a tile shrinks with its COLUMN, in W21 = -W22 T it grows with its ROW).  In the kernel's
+// row-major default the last tiles dispatched include the longest ones, and the launch ends with one long tile's time on a
+// nearly empty chip (1-2 ms of the top level's 10 ms at config 4); longest-first leaves only short tiles for the tail.
+const int2 *DenseSolver::trtri_tile_order(int tm, int tn, int kind) {
+    const long key = ((long)kind << 40) | ((long)tm << 20) | tn;
+    auto it = trtri_maps.find(key);
+    if (it != trtri_maps.end()) return it->second;
+    std::vector<int2> m;
+    m.reserve((size_t)tm * tn);
+    if (kind == 0) {            // KMODE_GE_COL: column 0 has the longest k-range
+        for (int j = 0; j < tn; j++)
+            for (int i = 0; i < tm; i++) m.push_back(make_int2(i, j));
+    } else {                    // KMODE_LE_ROW: the last row has the longest k-range
+        for (int i = tm - 1; i >= 0; i--)
+            for (int j = 0; j < tn; j++) m.push_back(make_int2(i, j));
+    }
+    int2 *d = nullptr;
+    if (hipMalloc(&d, m.size() * sizeof(int2)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, m.data(), m.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) { hipFree(d); return nullptr; }
+    trtri_maps.emplace(key, d);
+    return d;
+}
+
 hipError_t DenseSolver::trtri() {
     const int nb = nfact / 128;
     if (!Q) return hipErrorInvalidValue;
+    static const bool lpt = !getenv("JAICOV_TRTRI_ROWMAJOR");
     HIPCHK(hipMemsetAsync(W, 0, (size_t)n * ld * sizeof(double), stream));
     hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(nb), dim3(256), 0, stream, invd, W, ld);
     for (int h = 1; h < nb; h *= 2) {
@@ -674,6 +701,7 @@ hipError_t DenseSolver::trtri() {
             t.C = Q + (long)(mid * 128) * ld + lo * 128; t.ldc = ld;
             t.M = M; t.N = N; t.K = N; t.alpha = 1.0; t.beta = 0.0; t.kmode = KMODE_GE_COL;
             t.strideA = t.strideB = t.strideC = pair_stride;
+            if (lpt && (M / 128) * (N / 128) >= 64) { t.tile_map = trtri_tile_order(M / 128, N / 128, 0); t.n_map = t.tile_map ? (M / 128) * (N / 128) : 0; }
             HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, t, batch));
             GemmArgs w{};
             w.A = W + (long)(mid * 128) * ld + mid * 128; w.lda = ld;         // W22 (KC), lower-triangular
@@ -681,6 +709,7 @@ hipError_t DenseSolver::trtri() {
             w.C = W + (long)(mid * 128) * ld + lo * 128; w.ldc = ld;
             w.M = M; w.N = N; w.K = M; w.alpha = -1.0; w.beta = 0.0; w.kmode = KMODE_LE_ROW;
             w.strideA = w.strideB = w.strideC = pair_stride;
+            if (lpt && (M / 128) * (N / 128) >= 64) { w.tile_map = trtri_tile_order(M / 128, N / 128, 1); w.n_map = w.tile_map ? (M / 128) * (N / 128) : 0; }
             return gemm_f64(stream, LAY_KC, LAY_XC, w, batch);
         };
         if (full > 0) HIPCHK(merge(0, h, 2 * h, full));
