@@ -510,13 +510,14 @@ struct PPData {           // what one thread needs of one partner point q
 
 template <bool FUSED>
 __device__ __forceinline__ void pp_load(PPData<FUSED> &d, const DevProblem &p, const PPRecord &r, const int32_t *__restrict__ ipcol,
-                                        const double *__restrict__ rowsA, const double *__restrict__ Ubuf, int q, int qend) {
+                                        const double *__restrict__ rowsA, const double *__restrict__ Ubuf, int q, int qend,
+                                        const double *__restrict__ ug) {
     const long S = p.n_ip;
     if (q < qend) {
         const int m = 2 * r.mp;
         const double *P = p.blk_w + r.poff + (long)(2 * r.lp) * m + 2 * q;
-        d.P0 = *reinterpret_cast<const d2_t *>(P);
-        d.P1 = *reinterpret_cast<const d2_t *>(P + m);
+        d.P0 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(P));      // streamed exactly once over the launch
+        d.P1 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(P + m));
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             d.cq[b] = ipcol[3 * (long)(r.ipb + q) + b];
@@ -524,9 +525,12 @@ __device__ __forceinline__ void pp_load(PPData<FUSED> &d, const DevProblem &p, c
             d.aq[2 * b + 1] = rowsA[(long)(2 * b + 1) * S + r.ipb + q];
         }
         if (FUSED) {
-            const d2_t *u = reinterpret_cast<const d2_t *>(Ubuf + (long)2 * (r.ipb + q) * 8);
+            // U in the gather's layout (schur.hip, blk_elim_kernel): six coalesced 16-byte loads, 8 cache lines per wave instruction.
+            // From the row-major U buffer (a lane per 128-byte record) every one of these instructions touched 64 lines: -0.38 ms.
+            (void)Ubuf;
+            const d2_t *u = reinterpret_cast<const d2_t *>(ug) + r.ipb + q;
 #pragma unroll
-            for (int k = 0; k < 3; k++) { d.uq[k] = u[k]; d.uq[3 + k] = u[4 + k]; }
+            for (int k = 0; k < 6; k++) d.uq[k] = u[(long)k * S];
         }
     } else {
         d.cq[0] = d.cq[1] = d.cq[2] = -1;
@@ -562,7 +566,7 @@ __device__ __forceinline__ void pp_spread_row(double rowvec, double sigma2, doub
 
 template <bool FUSED>
 __device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const double (&ap)[6], const double (&up)[12], double sigma2,
-                                              double *strip, int c0, int cp0, int cp1, int cp2, int wlo = 0, int whi = PP_CW) {
+                                              double *strip, int cw, int c0, int cp0, int cp1, int cp2, int wlo, int whi) {
     double p00 = d.P0.x, p01 = d.P0.y, p10 = d.P1.x, p11 = d.P1.y;
     if (FUSED) {
         p00 *= sigma2; p01 *= sigma2; p10 *= sigma2; p11 *= sigma2;
@@ -581,8 +585,8 @@ __device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const doub
         const double g0 = p00 * d.aq[2 * b] + p01 * d.aq[2 * b + 1];
         const double g1 = p10 * d.aq[2 * b] + p11 * d.aq[2 * b + 1];
         if (cp0 >= cq) unsafeAtomicAdd(&strip[cq - c0], ap[0] * g0 + ap[1] * g1);
-        if (cp1 >= cq) unsafeAtomicAdd(&strip[PP_CW + cq - c0], ap[2] * g0 + ap[3] * g1);
-        if (cp2 >= cq) unsafeAtomicAdd(&strip[2 * PP_CW + cq - c0], ap[4] * g0 + ap[5] * g1);
+        if (cp1 >= cq) unsafeAtomicAdd(&strip[cw + cq - c0], ap[2] * g0 + ap[3] * g1);
+        if (cp2 >= cq) unsafeAtomicAdd(&strip[2 * cw + cq - c0], ap[4] * g0 + ap[5] * g1);
     }
 }
 
@@ -607,24 +611,41 @@ __device__ __forceinline__ int2 pp_range(const int2 *range, long idx) {
 template <bool FUSED, bool DET = false>
 __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             const double *__restrict__ Ubuf, double sigma2, double *__restrict__ N) {
-    __shared__ double strip[3 * PP_CW];
+    extern __shared__ double strip[];              // 3 rows x cw columns
     constexpr int NW = PP_NT / 64;
-    const int pt = blockIdx.x, tid = threadIdx.x, lane = tid & 63, chunk = blockIdx.y, nch = pp.n_chunks;
+    const int tid = threadIdx.x, lane = tid & 63, nch = pp.n_chunks, cw = pp.cw;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = pp.cmin + chunk * PP_CW;
+    // Which (point, chunk).  Default: grid (points, chunks).  xcd_map: a 1-D grid in which block b belongs to XCD b % 8 (workgroups
+    // are dealt round-robin to the XCDs: an observation used for speed only, every (point, chunk) is computed exactly once whatever
+    // the placement) and every XCD walks its OWN chunks one after the other, all points of a chunk in order.  The partner records
+    // of a chunk -- A_q, U_q, columns: 156 B per image point, ~2.4 MB per chunk of 960 columns at config 4, re-read by every row
+    // point of the image -- then stay in that XCD's 4 MB L2 instead of being fetched from the Infinity Cache / HBM by all eight
+    // (11 GB of fetches per launch against 2.9 GB algorithmic before).  Chunks are dealt boustrophedon (0..7, 15..8, 16..23, ...)
+    // because the work of a chunk falls with its index (lower triangle).
+    int pt, chunk;
+    if (pp.xcd_map) {
+        const int b = blockIdx.x, xcd = b & 7, sl = b >> 3;
+        const int kth = sl / p.n_points;
+        pt = sl - kth * p.n_points;
+        chunk = 8 * kth + ((kth & 1) ? 7 - xcd : xcd);
+        if (chunk >= nch) return;
+    } else {
+        pt = blockIdx.x; chunk = blockIdx.y;
+    }
+    const int c0 = pp.cmin + chunk * cw;
     const int cp0 = p.point_col[3 * pt], cp1 = p.point_col[3 * pt + 1], cp2 = p.point_col[3 * pt + 2];
     const int rmax = max(cp0, max(cp1, cp2));
     const int ob = pp.pt_ip_begin[pt], oe = pp.pt_ip_begin[pt + 1];
     if (rmax < c0 || (ob == oe && !(pp.plain && rmax <= pp.cmax))) return;   // plain mode: an unobserved point stores zeros
     const int2 *range = reinterpret_cast<const int2 *>(pp.range);
-    for (int i = tid; i < 3 * PP_CW; i += PP_NT) strip[i] = 0.0;
+    for (int i = tid; i < 3 * cw; i += PP_NT) strip[i] = 0.0;
     __syncthreads();
     // DET: every wave walks all images (step 1) with the ranges of ITS quarter of the strip's columns; else wave w takes every
     // NW-th image with the ranges of the whole chunk
     constexpr int STEP = DET ? 1 : NW;
     const int2 *rng = DET ? reinterpret_cast<const int2 *>(pp.range_sub) : range;
     const int nrc = DET ? 4 * nch : nch, rci = DET ? 4 * chunk + wave : chunk;
-    const int wlo = DET ? wave * (PP_CW / 4) : 0, whi = DET ? (wave + 1) * (PP_CW / 4) : PP_CW;
+    const int wlo = DET ? wave * (cw / 4) : 0, whi = DET ? (wave + 1) * (cw / 4) : cw;
     if (ob + (DET ? 0 : wave) < oe) {
         const int o0 = ob + (DET ? 0 : wave);
         PPRecord r1 = pp_record(pp.recs, o0);
@@ -632,9 +653,12 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
         const int o1 = min(o0 + STEP, oe - 1);
         PPRecord r2 = pp_record(pp.recs, o1);
         int2 g2 = pp_range(rng, (long)o1 * nrc + rci);
+        // (Measured alternatives, all slower than this form at config 4 -- assembly stage 3.05 ms before the coalesced copy of U:
+        // loads without the else branch 3.2-3.6 (the compiler then keeps old and new contents of the operand registers alive and
+        // spills), unconditional loads from clamped indices 3.3-3.7, two operand sets used alternately instead of the copy 3.6.)
         PPData<FUSED> cur, nxt;
         double apc[6], upc[12];
-        pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y);
+        pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y, pp.ug);
         pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
         for (int o = o0; o < oe; o += STEP) {
             const int o2 = min(o + 2 * STEP, oe - 1);
@@ -642,14 +666,14 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
             const int2 g3 = pp_range(rng, (long)o2 * nrc + rci);
             double rown = 0.0;
             if (o + STEP < oe) {
-                pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y);
+                pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y, pp.ug);
                 rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
             }
-            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2, wlo, whi);
+            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
             // ranges longer than a wave: the remaining passes without prefetch (into the registers of `cur`, which is done)
             for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
-                pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y);
-                pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, c0, cp0, cp1, cp2, wlo, whi);
+                pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y, pp.ug);
+                pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
             }
             cur = nxt;
             pp_spread_row<FUSED>(rown, sigma2, apc, upc);
@@ -662,13 +686,13 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     for (int a = 0; a < 3; a++) {
         const int r = cps[a];
         if (r < 0) continue;
-        const int cend = min(PP_CW, r - c0 + 1);
+        const int cend = min(cw, r - c0 + 1);
         double *nrow = N + (long)r * p.ld + c0;
         if (pp.plain) {
-            for (int c = tid; c < cend; c += PP_NT) nrow[c] = strip[a * PP_CW + c];
+            for (int c = tid; c < cend; c += PP_NT) nrow[c] = strip[a * cw + c];
         } else {
             for (int c = tid; c < cend; c += PP_NT) {
-                const double v = strip[a * PP_CW + c];
+                const double v = strip[a * cw + c];
                 if (v != 0.0) nrow[c] += v;
             }
         }
@@ -841,7 +865,7 @@ hipError_t launch_assemble_small(hipStream_t s, const DevProblem &p, const int32
 
 hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t *, int, int, const int32_t *, int,
                                   const double *, const double *, double *, double, double, double *, double *, double *,
-                                  double *, int *, double *, double *, const PPGather *);
+                                  double *, int *, double *, double *, const PPGather *, double *);
 
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
@@ -857,7 +881,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
         hipError_t he = launch_schur_eliminate(s, p, blk_list, n_list, max_m, ip_list, n_ip_list, rowsA, rowsW, T, sigma2,
                                                sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr, sb.xq,
-                                               pp.range_sub && pp.pt_ip_begin ? &pp : nullptr);
+                                               pp.range_sub && pp.pt_ip_begin ? &pp : nullptr, sb.Ug);
         if (he != hipSuccess) return he;
         if (sb.materialise) q.blk_w = sb.Pp;
         s2 = 1.0;
@@ -890,14 +914,16 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         if (he != hipSuccess) return he;
     }
     if (pp.pt_ip_begin) {
-        const dim3 gg(p.n_points, pp.n_chunks), gb(PP_NT);
+        const dim3 gg = pp.xcd_map ? dim3((unsigned)(8 * p.n_points * ((pp.n_chunks + 7) / 8))) : dim3(p.n_points, pp.n_chunks);
+        const dim3 gb(PP_NT);
+        const size_t lds = (size_t)3 * pp.cw * sizeof(double);
         const bool det = pp.range_sub != nullptr;
         if (schur && !sb.materialise) {   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
-            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, 0, s, p, pp, rowsA, sb.U, sigma2, N);
-            else hipLaunchKernelGGL((blk_pp_gather_kernel<true, false>), gg, gb, 0, s, p, pp, rowsA, sb.U, sigma2, N);
+            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
+            else hipLaunchKernelGGL((blk_pp_gather_kernel<true, false>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
         } else {
-            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<false, true>), gg, gb, 0, s, q, pp, rowsA, (const double *)nullptr, s2, N);
-            else hipLaunchKernelGGL((blk_pp_gather_kernel<false, false>), gg, gb, 0, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<false, true>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+            else hipLaunchKernelGGL((blk_pp_gather_kernel<false, false>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
         }
     } else {
         if (schur && !sb.materialise) return hipErrorInvalidValue;   // the per-pair atomic kernel reads a materialised P'

@@ -49,7 +49,7 @@ struct PPRecord {          // one (object point, image block) incidence, 32 byte
 #ifndef JAICOV_PP_NT
 #define JAICOV_PP_NT 256
 #endif
-constexpr int PP_CW = JAICOV_PP_CW;   // columns of one LDS strip of the point x point gather (3 rows x PP_CW doubles = 39 KB)
+constexpr int PP_CW = JAICOV_PP_CW;   // DEFAULT columns of one LDS strip of the point x point gather (3 rows x cw doubles of LDS; PPGather::cw)
 constexpr int PP_NT = JAICOV_PP_NT;   // threads per workgroup of the gather
 struct PPGather {
     const int32_t *pt_ip_begin = nullptr;   // [n_points+1] CSR over recs
@@ -60,6 +60,9 @@ struct PPGather {
     // only the lower triangle is assembled)
     const int32_t *range = nullptr;
     int cmin = 0, n_chunks = 0;
+    int cw = PP_CW;            // columns of one LDS strip (runtime: JAICOV_PP_CW; multiple of 4, the LDS strip is 3 * cw doubles)
+    const double *ug = nullptr; // SchurBufs::Ug (coalesced U_q loads) or null: read U_q from the row-major U buffer
+    int xcd_map = 0;           // != 0: 1-D grid, every XCD works on its own chunks only (blk_pp_gather_kernel)
     // plain != 0: the rows cmin..cmax of N are point rows only and nobody else has written their columns >= cmin yet;
     // the strips are then STORED (zeros included) instead of added, which saves zeroing that part of N and reading it back
     int cmax = -1, plain = 0;
@@ -72,6 +75,7 @@ struct PPGather {
 // buffers of the per-image EO pre-elimination (schur.hip); Pp == nullptr -> mode off
 struct SchurBufs {
     double *U = nullptr, *Linv = nullptr, *G = nullptr, *Pp = nullptr, *diagcorr = nullptr;
+    double *Ug = nullptr;     // the same U once more, laid out for the point x point gather: [6][n_ip] pairs (see blk_elim_kernel); may be null
     double *xq = nullptr;     // [6 * images] n_E / diag(N_EE): what the reference's REDUCED last pass leaves in dx (engine option)
     int *info = nullptr;
     double lambda = 0.0;

@@ -587,7 +587,13 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             for (int ip : blk_ip_list)
                 for (int a = 0; a < 3; a++) ipcol[(size_t)3 * ip + a] = D->point_col[3 * D->ip_point[ip] + a];
             // per record and column chunk: the range of partner positions (the block is stored in column order)
-            const int n_chunks = (cmax - cmin + PP_CW) / PP_CW;
+            int cw_rt = getenv("JAICOV_PP_CW") ? atoi(getenv("JAICOV_PP_CW")) : PP_CW;
+            cw_rt = std::max(64, std::min(cw_rt, 6400)) / 4 * 4;           // 3 * cw doubles of LDS (<= 150 KB), quarters for the DET form
+            e->pp.cw = cw_rt;
+            // XCD-partitioned block order (assemble.hip): measured no faster (3.24 vs 3.26 ms at 960 columns, slower where the chunks
+            // do not divide evenly over eight XCDs) and FETCH_SIZE fell by 6 % only: the partner records are not what the kernel waits for
+            e->pp.xcd_map = getenv("JAICOV_PP_XCD") ? atoi(getenv("JAICOV_PP_XCD")) : 0;
+            const int n_chunks = (cmax - cmin + cw_rt) / cw_rt;
             const int NOCOL = 1 << 30;
             std::vector<int32_t> lo_col(D->n_image_points, NOCOL), hi_col(D->n_image_points, -1);
             for (int ip : blk_ip_list)
@@ -603,7 +609,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
                 for (int j = 1; j < mp; j++)
                     if (lo_col[ipb + j] < lo_col[ipb + j - 1]) FAIL(e, JAICOV_ERR_DEVICE, "internal: dense block not in column order");
                 for (int c = 0; c < n_chunks; c++) {
-                    const int c0 = cmin + c * PP_CW, c1 = c0 + PP_CW;
+                    const int c0 = cmin + c * cw_rt, c1 = c0 + cw_rt;
                     int lo = mp, hi = 0;
                     for (int j = 0; j < mp; j++)
                         if (hi_col[ipb + j] >= c0 && lo_col[ipb + j] < c1) { lo = std::min(lo, j); hi = j + 1; }
@@ -628,7 +634,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = upload(e, range.data(), range.size(), &e->pp.range))) return rc;
             if (e->deterministic) {
                 // the same per SUB-chunk of PP_CW / 4 columns: one wave of the gather owns one (assemble.hip, DET)
-                const int CW4 = PP_CW / 4, n_sub = 4 * n_chunks;
+                const int CW4 = cw_rt / 4, n_sub = 4 * n_chunks;
                 std::vector<int32_t> sub_lo((size_t)blk_list.size() * n_sub), sub_hi((size_t)blk_list.size() * n_sub);
                 for (size_t t = 0; t < blk_list.size(); t++) {
                     const int g = blk_list[t], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
@@ -771,6 +777,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
         for (int g = 0; ok && g < D->n_image_blocks; g++) ok = D->blk_ip_begin[g + 1] - D->blk_ip_begin[g] >= 3;
         if (ok) {
             if ((rc = dalloc(e, (size_t)16 * std::max(1, D->n_image_points), &e->sb.U, true))) return rc;
+            if ((rc = dalloc(e, (size_t)12 * std::max(1, D->n_image_points), &e->sb.Ug, true))) return rc;   // U again, in the gather's layout
             if ((rc = dalloc(e, (size_t)36 * D->n_images, &e->sb.Linv, true))) return rc;
             if ((rc = dalloc(e, (size_t)6 * SCHUR_GLD * D->n_images, &e->sb.G, true))) return rc;
             // P' = sigma2 Dinv - U U' is formed inside the point x point gather; a copy in memory (4 GB at config 4) only on request
@@ -881,6 +888,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     } else {
         PPGather ppg = e->pp;
         ppg.plain = plain ? 1 : 0;
+        ppg.ug = sb.active ? sb.Ug : nullptr;
         HIPE(e, launch_assemble_blocks(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->max_m, e->d_blk_ip_list, e->n_blk_ip,
                                        e->d_rowsA, e->d_rowsW, e->d_T, sigma2, e->d_N, e->d_n, ppg, sb, e->d_cc_partial,
                                        e->solver.pstream, e->ev_fork, e->ev_join));   // side stream: the solver's (idle during the assembly)
@@ -1121,11 +1129,20 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         }
     }
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
-    HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    // This round trip stays even where nothing of it is needed before the factorisation (d = 0): with the host running ahead of
+    // the assembly -- enqueuing the factorisation and spinning in its residency handshake while the assembly kernels still run --
+    // every pass was 0.6 ms SLOWER (assembly +0.19, factorisation +0.4; measured A/B, JAICOV_EARLY_ENQUEUE=1 brings it back).
+    // What d = 0 does save is the round trip between the substitution and the first refinement step (`fast` below).
+    const bool fast = d == 0 && !getenv("JAICOV_NO_FAST_SOLVE");
+    static const bool early_enqueue = getenv("JAICOV_EARLY_ENQUEUE") != nullptr;
+    const bool presync = !(fast && early_enqueue);
     int hinfo = 0;   // status of the per-image EO eliminations, fetched in the same round trip
-    if (schur) HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    HIPE(e, hipStreamSynchronize(e->stream));
-    if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
+    if (presync) {
+        HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (schur) HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPE(e, hipStreamSynchronize(e->stream));
+        if (hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
+    }
     std::vector<double> Bh((size_t)8 * Upad, 0.0);
     double R[7] = {1, 1, 1, 1, 1, 1, 1};
     for (int a = 0; a < d; a++) {
@@ -1151,7 +1168,8 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     // factors on its stream while the rest of the matrix is still being scaled and copied (0.4 ms at config 4).
     // (in a loop: a dataflow factorisation that was abandoned -- cholflow.hip, "Visibility": a wait ran into its time limit, seen
     // about once in 1 000 factorisations at config 4 -- is repeated; N, V and the datum rows are untouched by it)
-    std::vector<double> X;
+    std::vector<double> X, delta0;
+    bool fast_refined = false;
     int info = 0;
     for (int attempt = 0;; attempt++) {
     if (!fused)
@@ -1174,6 +1192,33 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     HIPE(e, hipEventRecord(e->ev[6], e->stream));
     X.assign((size_t)nrhs * vs, 0.0);
     HIPE(e, hipMemcpyAsync(X.data(), e->d_G, X.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+    fast_refined = false;
+    if (fast && e->refine_steps >= 1 && !e->sim_built) {
+        // first refinement step without the host: dx = V y on the device, residual of the unscaled system in two-fold precision,
+        // forward + backward substitution (refine.hip, dense.hip); the correction comes back together with y
+        const int nbk = Up / 128;
+        const size_t need = (size_t)nbk * nbk * 256;
+        if (e->refP_len < need) {
+            if (e->d_refP) hipFree(e->d_refP);
+            e->d_refP = nullptr; e->refP_len = 0;
+            HIPE(e, hipMalloc(&e->d_refP, need * sizeof(double)));
+            e->refP_len = need;
+        }
+        double *d_rhs = e->d_ref, *d_tmp = e->d_ref + Upad, *d_delta = e->d_ref + 2 * (size_t)Upad;
+        HIPE(e, hipEventRecord(e->ev_r0, e->stream));
+        hipLaunchKernelGGL(scale_vec_kernel, dim3((Up + 255) / 256), dim3(256), 0, e->stream, e->d_G, e->d_V, e->d_dx, U, Up, 0);   // dx = V y
+        HIPE(e, launch_residual_dd(e->stream, e->d_N, (long)Upad, U, 0, Up, e->d_dx, e->d_n, e->d_V, e->d_Braw, e->d_B, (long)Upad,
+                                   RefineBorder{}, e->d_refP, d_rhs));
+        HIPE(e, slv.solve_rhs(d_rhs, d_tmp, d_delta));
+        HIPE(e, hipEventRecord(e->ev_r1, e->stream));
+        delta0.assign((size_t)Up, 0.0);
+        HIPE(e, hipMemcpyAsync(delta0.data(), d_delta, delta0.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        fast_refined = true;
+    }
+    if (!presync) {
+        HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+        if (schur) HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    }
     info = slv.fetch_info();
     if (info == -9 && attempt < 2) {
         ++e->flow_retries;
@@ -1182,6 +1227,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     break;
     }
+    if (!presync && hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
     if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation did not complete on the device (code " + std::to_string(info) + ")");
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "normal-equation matrix is singular / not positive definite at pivot " + std::to_string(info));
     // ---- rank-d border algebra on the host ---------------------------------------------------------------------
@@ -1221,7 +1267,18 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     // dk = S^-1 (Bh delta0 - r_k),  dy = delta0 - G^ dk.
     float refine_ms = 0.f;
     e->last_refine_correction = 0.0;
-    for (int step = 0; step < e->refine_steps && !e->sim_built; step++) {
+    if (fast_refined) {      // the step the device took on its own (d = 0: no border algebra): dx += V delta
+        hipEventElapsedTime(&refine_ms, e->ev_r0, e->ev_r1);
+        double cmax = 0.0, xmax = 0.0;
+        for (int c = 0; c < U; c++) {
+            const double corr = e->h_V[c] * delta0[c];
+            if (!std::isfinite(corr)) FAIL(e, JAICOV_ERR_NOT_FINITE, "non-finite refinement step");
+            dx_out[c] += corr;
+            cmax = std::max(cmax, fabs(corr)); xmax = std::max(xmax, fabs(dx_out[c]));
+        }
+        e->last_refine_correction = xmax > 0.0 ? cmax / xmax : 0.0;
+    }
+    for (int step = fast_refined ? 1 : 0; step < e->refine_steps && !e->sim_built; step++) {
         const int nbk = Up / 128;
         const size_t need = (size_t)nbk * nbk * 256;
         if (e->refP_len < need) {

@@ -22,7 +22,8 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
                                                        const double *__restrict__ rowsA, const double *__restrict__ rowsW,
                                                        const double *__restrict__ T, double sigma2, double lambda,
                                                        double *__restrict__ Ubuf, double *__restrict__ Linv_out,
-                                                       double *__restrict__ G_out, int *info, double *__restrict__ xq) {
+                                                       double *__restrict__ G_out, int *info, double *__restrict__ xq,
+                                                       double *__restrict__ Ug) {
     __shared__ double red[42];        // E (36) + nE (6)
     __shared__ double redw[4][42];    // per-wave partial sums: summed in wave order (LDS atomics would sum in arrival order)
     __shared__ double Linv[36];
@@ -106,12 +107,17 @@ __global__ __launch_bounds__(256) void blk_elim_kernel(DevProblem p, const int32
     for (int row = tid; row < m; row += 256) {
         const double *t = T + ((long)2 * ipb + row) * KC_LD;
         double *uo = Ubuf + ((long)2 * ipb + row) * 8;
+        // second copy for the point x point gather, where lane q of a wave reads the U rows of partner q: slot j of image point
+        // ip is the pair Ug[(j * n_ip + ip) * 2 + {0, 1}], j < 3: (U[2 ip][2 j], U[2 ip][2 j + 1]), j >= 3: the same of row 2 ip + 1
+        // -- consecutive lanes then read consecutive 16-byte pieces (8 cache lines per wave instruction instead of 64)
+        double *ug = Ug ? Ug + (((long)(3 * (row & 1)) * S + ipb + (row >> 1)) * 2) : nullptr;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             double s = 0.0;
 #pragma unroll
             for (int j = 0; j <= k; j++) s += t[3 + j] * Linv[6 * k + j];
             uo[k] = sigma2 * s;
+            if (ug) ug[(long)(k >> 1) * S * 2 + (k & 1)] = sigma2 * s;
         }
     }
     __threadfence_block();
@@ -396,10 +402,10 @@ hipError_t launch_schur_expand_f(hipStream_t s, const DevProblem &p, const int32
 hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double lambda, double *Ubuf, double *Linv, double *G,
-                                  double *Pp, int *info, double *diagcorr, double *xq, const PPGather *det_pp) {
+                                  double *Pp, int *info, double *diagcorr, double *xq, const PPGather *det_pp, double *Ug) {
     if (n_list <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_elim_kernel, dim3(n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T, sigma2, lambda, Ubuf,
-                       Linv, G, info, xq);
+                       Linv, G, info, xq, Ug);
     if (Pp)   // only when P' is wanted in memory (JAICOV_PP_MATERIALISE / the atomic point x point kernel); the gather forms it on the fly
         hipLaunchKernelGGL(blk_pprime_kernel, dim3((max_m + 63) / 64, (max_m + 63) / 64, n_list), dim3(64, 4), 0, s, p, blk_list,
                            Ubuf, sigma2, Pp);
