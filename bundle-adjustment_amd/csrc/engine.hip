@@ -68,9 +68,9 @@ __global__ void damp_and_precond_kernel(double *N, long ld, int U, int Upad, int
 
 // zero the lower triangle (row r: columns 0 .. r, rounded up to 4) of the leading `rows` rows; grid (ceil(rows/1024), rows)
 // rows skip_lo..skip_hi (the point rows the gather stores itself, PPGather::plain): only the columns before skip_lo
-__global__ __launch_bounds__(256) void zero_lower_kernel(double *__restrict__ N, long ld, int rows, int skip_lo, int skip_hi) {
-    const int r = blockIdx.y, c = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (c > r) return;
+__global__ __launch_bounds__(256) void zero_lower_kernel(double *__restrict__ N, long ld, int rows, int skip_lo, int skip_hi, int row0) {
+    const int r = row0 + blockIdx.y, c = 4 * (blockIdx.x * 256 + threadIdx.x);
+    if (c > r || r >= rows) return;
     if (r >= skip_lo && r <= skip_hi) {
         if (c >= skip_lo) return;
         if (c + 4 > skip_lo) {           // the quad straddles the first stored column
@@ -867,8 +867,19 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
     const bool plain = e->pp_plain_ok && !e->dense_mode && e->pp.pt_ip_begin != nullptr && e->n_blk_list > 0;
     {   // only the lower triangle of N is ever written or read (nadd, pack, scale_copy); the reduced system has e0 rows
         const int rows = e->schur_active ? std::min(e->Upad, ((e->e0 + 127) / 128) * 128) : e->Upad;
-        hipLaunchKernelGGL(zero_lower_kernel, dim3((rows + 1023) / 1024, rows), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, rows,
-                           plain ? e->pp.cmin : rows, plain ? e->pp.cmax : -1);
+        // three launches, each over the rows and columns that need zeroing only (one launch over the whole square spent 60 us at
+        // config 4 dispatching 226 000 workgroups of which 99.9 % returned at once): rows above the stored strips, the stored rows'
+        // columns before the first stored column (nothing when the points come first and there is no datum border), rows below
+        const int slo = plain ? e->pp.cmin : rows, shi = plain ? e->pp.cmax : -1;
+        auto zero_rows = [&](int r0, int r1, int cols) {
+            if (r1 > r0 && cols > 0)
+                hipLaunchKernelGGL(zero_lower_kernel, dim3((cols + 1023) / 1024, r1 - r0), dim3(256), 0, e->stream, e->d_N, (long)e->Upad, rows, slo, shi, r0);
+        };
+        zero_rows(0, std::min(slo, rows), std::min(slo, rows));
+        if (plain) {
+            zero_rows(slo, std::min(shi + 1, rows), slo);
+            zero_rows(std::min(shi + 1, rows), rows, rows);
+        }
         HIPE(e, hipMemsetAsync(e->d_N + sq, 0, (size_t)e->Upad * sizeof(double), e->stream));
     }
     if (!plain)
