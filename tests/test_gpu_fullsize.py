@@ -1,9 +1,10 @@
-"""GPU parity at BASELINE's full size (config 4/5: 500 images x 5 000 points, dense per-image dispersions, U = 18 014).
+"""Size-independent properties at BASELINE's full size (config 4/5: 500 images x 5 000 points, dense per-image dispersions,
+U = 18 014): independent device paths must agree with each other (EO-reduced vs full-order factorisation, structure-aware vs
+densified assembly, REDUCED vs FULL cofactor matrix), the solution must satisfy the normal equations it was computed from, the
+inverse must invert, and the converged adjustment must reproduce the noise level the scene was generated with.
 
-The CPU oracle needs ~400 s per pass at this size, so the checks are size-independent properties: independent device
-paths must agree with each other (EO-reduced vs full-order factorisation, structure-aware vs densified assembly,
-REDUCED vs FULL cofactor matrix), the solution must satisfy the normal equations it was computed from, the inverse
-must invert, and the converged adjustment must reproduce the noise level the scene was generated with."""
+The comparison with the ORACLE at this size -- single passes, and the loop run to the reference's termination criterion against the
+oracle's converged answer -- is in tests/test_gpu_cfg4_golden.py and tests/test_gpu_termination.py."""
 import numpy as np
 import pytest
 
@@ -40,7 +41,7 @@ def test_cfg4_converges_quadratically_and_is_idempotent(cfg4, converged):
     s2 = cfg4.sigma2apriori
     eng.build(s2, 0.0)
     dx = eng.solve(False)
-    assert np.abs(dx).max() < 1e-6                       # a further pass at the optimum does (numerically) nothing
+    assert np.abs(dx).max() <= 1.0536712127723509e-8     # the fourth pass meets the reference's criterion sqrt(eps) (BA:327-335); oracle: 1.2e-9
     om = eng.omega(s2, dx)
     assert abs(om / cfg4.degree_of_freedom / s2 - 1.0) < 0.02   # sigma0^2 a-posteriori reproduces the simulated noise level
 
