@@ -734,6 +734,10 @@ __global__ void scalebar_kernel(DevProblem p, const double *__restrict__ vals, d
 // directly observed groups (PDF:447-473): A is a selection matrix -> N[cols,cols] += P, n[cols] += P w
 // one workgroup per group
 // ---------------------------------------------------------------------------------------------------------------
+// Per-row data of the group (column, v = observed - value - dx) are staged in LDS by one thread per row FIRST: read inside the
+// row x column loops they were 45 dependent chains of five global loads each for a 45-row group -- 60 us of pure latency on the
+// critical path of every pass at config 4.  DIRECT_STAGE rows per group in LDS; longer groups read past it from memory.
+constexpr int DIRECT_STAGE = 2048;
 __global__ __launch_bounds__(256) void direct_kernel(DevProblem p, const double *__restrict__ vals, double sigma2,
                                                      double *N, double *n, const double *dx, double *omega) {
     const int g = blockIdx.x;
@@ -741,31 +745,39 @@ __global__ __launch_bounds__(256) void direct_kernel(DevProblem p, const double 
     const long woff = p.dg_w_offset[g];
     const double *W = woff >= 0 ? p.dg_w + woff : nullptr;
     __shared__ double red[256];
+    __shared__ double s_v[DIRECT_STAGE];
+    __shared__ int s_col[DIRECT_STAGE];
+    auto row_col = [&](int c) { return p.slot_col[p.dg_slot[b + c]]; };
+    auto row_v = [&](int c, int cc) {
+        double vc = p.dg_obs[b + c] - vals[p.dg_slot[b + c]];
+        if (dx && cc >= 0) vc -= dx[cc];
+        return vc;
+    };
+    for (int c = threadIdx.x; c < m && c < DIRECT_STAGE; c += 256) {
+        const int cc = row_col(c);
+        s_col[c] = cc;
+        s_v[c] = row_v(c, cc);
+    }
+    __syncthreads();
+    auto col_of = [&](int c) { return c < DIRECT_STAGE ? s_col[c] : row_col(c); };
+    auto v_of = [&](int c) { return c < DIRECT_STAGE ? s_v[c] : row_v(c, row_col(c)); };
     double om = 0.0;
     for (int r = threadIdx.x; r < m; r += 256) {
-        const int slot_r = p.dg_slot[b + r], cr = p.slot_col[slot_r];
+        const int cr = col_of(r);
+        const double vr = v_of(r);
         double pw = 0.0;    // (P v)[r], v = w - A dx
         if (W) {
-            for (int c = 0; c < m; c++) {
-                const int sc = p.dg_slot[b + c], cc = p.slot_col[sc];
-                double vc = p.dg_obs[b + c] - vals[sc];
-                if (dx && cc >= 0) vc -= dx[cc];
-                pw += sigma2 * W[(long)r * m + c] * vc;
-            }
+            for (int c = 0; c < m; c++) pw += sigma2 * W[(long)r * m + c] * v_of(c);
         } else {
-            double vr = p.dg_obs[b + r] - vals[slot_r];
-            if (dx && cr >= 0) vr -= dx[cr];
             pw = sigma2 / p.dg_var[b + r] * vr;
         }
         if (dx) {
-            double vr = p.dg_obs[b + r] - vals[slot_r];
-            if (cr >= 0) vr -= dx[cr];
             om += vr * pw;
         } else if (cr >= 0) {
             unsafeAtomicAdd(n + cr, pw);
             if (W) {
                 for (int c = 0; c <= r; c++) {
-                    const int cc = p.slot_col[p.dg_slot[b + c]];
+                    const int cc = col_of(c);
                     if (cc >= 0) nadd(N, p.ld, cr, cc, sigma2 * W[(long)r * m + c]);
                 }
             } else {
@@ -867,6 +879,8 @@ hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t
                                   const double *, const double *, double *, double, double, double *, double *, double *,
                                   double *, int *, double *, double *, const PPGather *, double *);
 
+hipError_t launch_schur_tfix(hipStream_t, const DevProblem &, const int32_t *, int, const double *, const double *, double, double *);
+
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb,
@@ -894,9 +908,21 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     const bool no_fork = getenv("JAICOV_NO_ASSEMBLY_FORK") != nullptr;
     const bool fork = side && ev_fork && ev_join && pp.pt_ip_begin && !no_fork;
     hipStream_t cs = fork ? side : s;
+    // T' = sigma2 T - U (U' A_c) is needed by the camera-side kernels only, so it could run on their side stream beside the gather
+    // (JAICOV_TFIX_SIDE=1).  Measured at config 4: assembly 2.84 ms that way against 2.80 ms with T' in front of the fork -- the
+    // gather loses more to the company than the critical path gains.
+    static const bool tfix_main = getenv("JAICOV_TFIX_SIDE") == nullptr;
+    if (schur && tfix_main) {
+        hipError_t he = launch_schur_tfix(s, p, ip_list, n_ip_list, sb.U, sb.G, sigma2, T);
+        if (he != hipSuccess) return he;
+    }
     if (fork) {
         hipError_t he = hipEventRecord(ev_fork, s);
         if (he == hipSuccess) he = hipStreamWaitEvent(side, ev_fork, 0);
+        if (he != hipSuccess) return he;
+    }
+    if (schur && !tfix_main) {      // T' for the camera-side kernels that follow on this stream
+        hipError_t he = launch_schur_tfix(cs, p, ip_list, n_ip_list, sb.U, sb.G, sigma2, T);
         if (he != hipSuccess) return he;
     }
     hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, cs, p, blk_list, rowsA, T, s2, cc_partial, schur);

@@ -418,7 +418,15 @@ hipError_t launch_schur_eliminate(hipStream_t s, const DevProblem &p, const int3
         hipLaunchKernelGGL(blk_diagcorr_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, p, ip_list, n_ip_list,
                            blk_list, n_list, rowsA, Ubuf, G, diagcorr);
     }
+    return hipGetLastError();
+}
+
+// T' = sigma2 T - U (U' A_c): needed by the camera-side kernels only (the point x point gather forms P' from D^-1 and U); where it is
+// launched -- in front of the fork or on the side stream -- is the caller's choice (assemble.hip, launch_assemble_blocks)
+hipError_t launch_schur_tfix(hipStream_t s, const DevProblem &p, const int32_t *ip_list, int n_ip_list, const double *Ubuf,
+                             const double *G, double sigma2, double *T) {
     const long tot = (long)2 * n_ip_list;
+    if (tot <= 0) return hipSuccess;
     hipLaunchKernelGGL(blk_tfix_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, p, ip_list, n_ip_list, Ubuf, G,
                        sigma2, T);
     return hipGetLastError();
