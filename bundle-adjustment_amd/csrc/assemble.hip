@@ -640,14 +640,14 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     const int2 *range = reinterpret_cast<const int2 *>(pp.range);
     for (int i = tid; i < 3 * cw; i += PP_NT) strip[i] = 0.0;
     __syncthreads();
-    // DET: every wave walks all images (step 1) with the ranges of ITS quarter of the strip's columns; else wave w takes every
-    // NW-th image with the ranges of the whole chunk
-    constexpr int STEP = DET ? 1 : NW;
-    const int2 *rng = DET ? reinterpret_cast<const int2 *>(pp.range_sub) : range;
-    const int nrc = DET ? 4 * nch : nch, rci = DET ? 4 * chunk + wave : chunk;
-    const int wlo = DET ? wave * (cw / 4) : 0, whi = DET ? (wave + 1) * (cw / 4) : cw;
-    if (ob + (DET ? 0 : wave) < oe) {
-        const int o0 = ob + (DET ? 0 : wave);
+    // Wave w takes every NW-th image of the point, with the partner ranges of the whole chunk.
+    constexpr int STEP = NW;
+    const int2 *rng = range;
+    const int nrc = nch, rci = chunk;
+    const int wlo = 0, whi = cw;
+    if constexpr (!DET) {
+    if (ob + wave < oe) {
+        const int o0 = ob + wave;
         PPRecord r1 = pp_record(pp.recs, o0);
         int2 g1 = pp_range(rng, (long)o0 * nrc + rci);
         const int o1 = min(o0 + STEP, oe - 1);
@@ -678,6 +678,53 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
             cur = nxt;
             pp_spread_row<FUSED>(rown, sigma2, apc, upc);
             r1 = r2; g1 = g2; r2 = r3; g2 = g3;
+        }
+    }
+    } else {
+        // DETERMINISTIC form: the same distribution of the images over the waves and the same prefetching, but the waves ADD in
+        // turn -- round r: wave 0 adds image 4r, then wave 1 image 4r + 1, ... with a workgroup barrier after every turn -- so
+        // every entry of the strip is summed in image order whatever the timing.  The loads of all four waves still overlap; what
+        // the barriers cost is the waves' freedom to run ahead of each other.  (Round 2's form gave every wave a quarter of the
+        // strip's columns and let it walk ALL images: four times the records, row fetches and range look-ups at a quarter of the
+        // lanes: +1.7 ms per pass at config 4.  Both forms sum in image order: identical bits.)
+        const int rounds = (oe - ob + NW - 1) / NW;       // the same for every wave: the barriers below are reached by all
+        if (rounds > 0) {
+            const int o0 = ob + wave;
+            const int oc0 = min(o0, oe - 1);
+            PPRecord r1 = pp_record(pp.recs, oc0);
+            int2 g1 = pp_range(rng, (long)oc0 * nrc + rci);
+            if (o0 >= oe) g1.y = g1.x;
+            const int o1 = min(o0 + STEP, oe - 1);
+            PPRecord r2 = pp_record(pp.recs, o1);
+            int2 g2 = pp_range(rng, (long)o1 * nrc + rci);
+            PPData<FUSED> cur, nxt;
+            double apc[6], upc[12];
+            pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y, pp.ug);
+            pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
+            int o = o0;
+            for (int rd = 0; rd < rounds; rd++, o += STEP) {
+                const int o2 = min(o + 2 * STEP, oe - 1);
+                const PPRecord r3 = pp_record(pp.recs, o2);
+                const int2 g3 = pp_range(rng, (long)o2 * nrc + rci);
+                double rown = 0.0;
+                if (o + STEP < oe) {
+                    pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y, pp.ug);
+                    rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
+                }
+                for (int turn = 0; turn < NW; turn++) {
+                    if (turn == wave && o < oe) {
+                        pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
+                        for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
+                            pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y, pp.ug);
+                            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
+                        }
+                    }
+                    __syncthreads();
+                }
+                cur = nxt;
+                pp_spread_row<FUSED>(rown, sigma2, apc, upc);
+                r1 = r2; g1 = g2; r2 = r3; g2 = g3;
+            }
         }
     }
     __syncthreads();
@@ -895,7 +942,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
         hipError_t he = launch_schur_eliminate(s, p, blk_list, n_list, max_m, ip_list, n_ip_list, rowsA, rowsW, T, sigma2,
                                                sb.lambda, sb.U, sb.Linv, sb.G, sb.materialise ? sb.Pp : nullptr, sb.info, sb.diagcorr, sb.xq,
-                                               pp.range_sub && pp.pt_ip_begin ? &pp : nullptr, sb.Ug);
+                                               pp.det && pp.pt_ip_begin ? &pp : nullptr, sb.Ug);
         if (he != hipSuccess) return he;
         if (sb.materialise) q.blk_w = sb.Pp;
         s2 = 1.0;
@@ -943,7 +990,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         const dim3 gg = pp.xcd_map ? dim3((unsigned)(8 * p.n_points * ((pp.n_chunks + 7) / 8))) : dim3(p.n_points, pp.n_chunks);
         const dim3 gb(PP_NT);
         const size_t lds = (size_t)3 * pp.cw * sizeof(double);
-        const bool det = pp.range_sub != nullptr;
+        const bool det = pp.det != 0;
         if (schur && !sb.materialise) {   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
             if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
             else hipLaunchKernelGGL((blk_pp_gather_kernel<true, false>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);

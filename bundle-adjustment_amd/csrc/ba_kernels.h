@@ -66,10 +66,8 @@ struct PPGather {
     // plain != 0: the rows cmin..cmax of N are point rows only and nobody else has written their columns >= cmin yet;
     // the strips are then STORED (zeros included) instead of added, which saves zeroing that part of N and reading it back
     int cmax = -1, plain = 0;
-    // deterministic variant: ranges per record and SUB-chunk of PP_CW / 4 columns (range_sub[2 * (o * 4 * n_chunks + 4 * chunk + w)]):
-    // wave w of a workgroup owns the w-th quarter of the strip's columns and walks ALL images of the point in order, so every
-    // entry of N is summed in image order whatever the timing (null: the free-running variant, sums in arrival order)
-    const int32_t *range_sub = nullptr;
+    // deterministic variant (engine option): the waves of a workgroup add their images' products to the strip in turn, image order
+    int det = 0;
 };
 
 // buffers of the per-image EO pre-elimination (schur.hip); Pp == nullptr -> mode off

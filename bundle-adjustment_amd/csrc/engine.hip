@@ -632,33 +632,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = upload(e, recs.data(), recs.size(), &e->pp.recs))) return rc;
             if ((rc = upload(e, ipcol.data(), ipcol.size(), &e->pp.ipcol))) return rc;
             if ((rc = upload(e, range.data(), range.size(), &e->pp.range))) return rc;
-            if (e->deterministic) {
-                // the same per SUB-chunk of PP_CW / 4 columns: one wave of the gather owns one (assemble.hip, DET)
-                const int CW4 = cw_rt / 4, n_sub = 4 * n_chunks;
-                std::vector<int32_t> sub_lo((size_t)blk_list.size() * n_sub), sub_hi((size_t)blk_list.size() * n_sub);
-                for (size_t t = 0; t < blk_list.size(); t++) {
-                    const int g = blk_list[t], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
-                    for (int c = 0; c < n_sub; c++) {
-                        const int c0 = cmin + c * CW4, c1 = c0 + CW4;
-                        int lo = mp, hi = 0;
-                        for (int j = 0; j < mp; j++)
-                            if (hi_col[ipb + j] >= c0 && lo_col[ipb + j] < c1) { lo = std::min(lo, j); hi = j + 1; }
-                        sub_lo[t * n_sub + c] = lo; sub_hi[t * n_sub + c] = std::max(hi, lo);
-                    }
-                }
-                std::vector<int32_t> range_sub((size_t)2 * list.size() * n_sub);
-                for (size_t o = 0; o < list.size(); o++) {
-                    const int ip = list[o], g = blk_of_ip[ip], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
-                    const int t = blk_pos[g];
-                    const int qend = (int)(std::upper_bound(lo_col.begin() + ipb, lo_col.begin() + ipb + mp, hi_col[ip]) - (lo_col.begin() + ipb));
-                    for (int c = 0; c < n_sub; c++) {
-                        const int lo = sub_lo[(size_t)t * n_sub + c], hi = std::min(sub_hi[(size_t)t * n_sub + c], qend);
-                        range_sub[2 * (o * n_sub + c)] = lo;
-                        range_sub[2 * (o * n_sub + c) + 1] = std::max(hi, lo);
-                    }
-                }
-                if ((rc = upload(e, range_sub.data(), range_sub.size(), &e->pp.range_sub))) return rc;
-            }
+            e->pp.det = e->deterministic ? 1 : 0;
             e->pp.cmin = cmin;
             e->pp.n_chunks = n_chunks;
             e->pp.cmax = cmax;

@@ -161,8 +161,8 @@ typedef struct jaicov_engine_options {
                                       runs give the same bits in N and n.  The default lets the four waves of a workgroup of the
                                       point x point gather add their images' terms in arrival order (LDS fp64 atomics): ~1e-16 relative
                                       differences in N from run to run, which cond(N) ~ 1e9 turns into ~1e-9 in Qxx on the smallest
-                                      test scenes.  Costs 1.4 ms per pass at config 4 (assembly 3.5 -> 5.0 ms: every wave of the gather then
-                                      walks all images of its point).  JAICOV_DETERMINISTIC=0/1 overrides.                              */
+                                      test scenes.  Costs 0.7 ms per pass at config 4 (assembly 2.8 -> 3.5 ms: the waves then add in turn,
+                                      a workgroup barrier after every turn; round 2's form cost 1.7 ms).  JAICOV_DETERMINISTIC=0/1 overrides. */
     int32_t  refinement;           /* iterative refinement of the step in jaicov_neq_solve: 0 = default (ONE step), < 0 = none, k > 0 = k steps
                                       (at most 4).  A step computes the residual n - N dx (and the datum border's) of the unscaled system
                                       in two-fold precision on the device and solves for the correction with the factor at hand (one forward
