@@ -101,7 +101,8 @@ def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
     eng.finalize(sigma2, lam)
     dx = eng.solve(invert)
     e0 = eng.reduced_order()
-    if e0 < eng.U and dist.get_world_size() > 1:
+    import os
+    if e0 < eng.U and (dist.get_world_size() > 1 or os.environ.get("JAICOV_FORCE_EO_EXCHANGE")):   # the switch: rehearsal on one rank
         if device is not None and torch.device(device).type == "cuda" and dist.get_backend() == "nccl":
             # the EO steps stay where the back-substitution left them: all-reduce the engine's device array in place, one copy back
             ptr, cnt = eng.eo_step_buffer()

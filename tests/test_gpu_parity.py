@@ -406,6 +406,17 @@ def test_rccl_reduce_path_world1(oracle_mod):
         eng.set_parameters(fp.values)
         dx = distributed.sharded_step(eng, dist, torch.device("cuda", 0), s2)
         np.testing.assert_allclose(dx, dx_ref, rtol=0, atol=1e-8 * np.abs(dx_ref).max())   # fp64 atomics: summation order differs run to run
+        # the exchange of the pre-eliminated EO steps (all-reduce in place on the engine's device array, jaicov_neq_eo_step_buffer)
+        # runs only with more than one rank: rehearsed here on one
+        assert eng.reduced_order() < eng.U
+        os.environ["JAICOV_FORCE_EO_EXCHANGE"] = "1"
+        try:
+            dx2 = distributed.sharded_step(eng, dist, torch.device("cuda", 0), s2)
+        finally:
+            del os.environ["JAICOV_FORCE_EO_EXCHANGE"]
+        np.testing.assert_allclose(dx2, dx_ref, rtol=0, atol=1e-8 * np.abs(dx_ref).max())
+        ptr, cnt = eng.eo_step_buffer()
+        assert ptr and cnt == 6 * fp.n_images
         eng.close()
     finally:
         dist.destroy_process_group()
