@@ -295,7 +295,7 @@ def main():
             out["kernel_resources"] = {"source": "csrc/kernel_resources.json (hipcc -Rpass-analysis=kernel-resource-usage of the shipped build)",
                                        "kernels_with_vgpr_spills": sorted(k for k, v in tab.items() if v["vgpr_spills"]),
                                        "lm_pass": tab,
-                                       "note": "potrf_chain_kernel's scratch is the frame of its two companion roles (real calls, entered once per launch); the chain loop has no scratch access"}
+                                       "kernels_with_scratch": sorted(k for k, v in tab.items() if v["scratch_bytes_per_lane"])}
         except Exception:
             pass
         if world >= 1:

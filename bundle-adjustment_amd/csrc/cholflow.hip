@@ -712,10 +712,10 @@ __device__ __forceinline__ void chain_factor(double *Acc, long ld, int *info, in
     }
 }
 
-// The companion roles of the chain kernel as REAL calls (noinline): inlined, their register appetite (the inverse wants most of
-// the 512) joined the chain role's in one allocation and the chain loop -- the critical path of the whole factorisation -- spilled
-// (28 VGPRs, 100 bytes of scratch per lane).  A role is entered once per launch, so the call costs nothing.
-__device__ __attribute__((noinline)) void chain_role_inverses(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
+// The companion roles of the chain kernel (entered once per launch, by workgroups 1 and 2).  Round 2's build spilled 28 VGPRs inside
+// the chain loop; what removed them was moving ONE load in chain_solve_update (the diagonal tile after the solve instead of
+// before it).  Making the roles real calls was tried on the way and is not needed: it bought nothing and cost a 744-byte call frame.
+__device__ __forceinline__ void chain_role_inverses(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
     const FlowArgs &g = *gp;
     const int tid = threadIdx.x;
     // ---- the inverses ----------------------------------------------------------------------------------------------
@@ -757,7 +757,7 @@ __device__ __attribute__((noinline)) void chain_role_inverses(const FlowArgs *gp
     }
     return;
 }
-__device__ __attribute__((noinline)) void chain_role_second(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
+__device__ __forceinline__ void chain_role_second(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
     const FlowArgs &g = *gp;
     const int tid = threadIdx.x;
     // ---- the second subdiagonal: workgroup 2 finishes tile (c+2, c) by the same block forward substitution as the chain
@@ -853,10 +853,8 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
         // ... then: resident, the tile kernel may come
         if (g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // (the roles read the arguments where the dispatch packet put them: taking the address of `g` would copy the struct to the stack
-    // and send every later g.field of the chain loop through scratch)
-    if (blockIdx.x == 1) { chain_role_inverses((const FlowArgs *)__builtin_amdgcn_kernarg_segment_ptr(), S, Wd, &s_ok); return; }
-    if (blockIdx.x == 2) { chain_role_second((const FlowArgs *)__builtin_amdgcn_kernarg_segment_ptr(), S, Wd, &s_ok); return; }
+    if (blockIdx.x == 1) { chain_role_inverses(&g, S, Wd, &s_ok); return; }
+    if (blockIdx.x == 2) { chain_role_second(&g, S, Wd, &s_ok); return; }
     // ---- the chain -------------------------------------------------------------------------------------------------
     if (tid == 0) {
         const bool r = flow_spin(g.applied, 1, g.ctrl, g.timeout, nullptr);      // tile (0, 0): scaled, in L
