@@ -972,7 +972,12 @@ static int ensure_inverse_buffers(jaicov_engine *e, bool reduced_system) {
 
 // FULL_EXPANDED is FULL wherever the expansion cannot be done: no EO pre-elimination, or an engine that sees a shard of the images
 static int effective_invert(const jaicov_engine *e, int invert) {
-    if (invert == JAICOV_INVERT_FULL_EXPANDED && !(e->schur_ok && e->all_images && !getenv("JAICOV_FULL_LITERAL"))) return JAICOV_INVERT_FULL;
+    if (invert != JAICOV_INVERT_FULL_EXPANDED) return invert;
+    if (!(e->schur_ok && e->all_images && e->solverS_ready && !getenv("JAICOV_FULL_LITERAL"))) return JAICOV_INVERT_FULL;
+    // the expansion's workspace is the reduced solver's W square: F and T1 ([6 images, padded] x order) and T2 must fit (they do
+    // unless the exterior orientations outnumber the other unknowns several times over: then the literal route is taken)
+    const size_t I6p = ((size_t)6 * e->p.n_images + 127) / 128 * 128, Up = (size_t)e->solverS.nfact;
+    if (I6p * (2 * Up + I6p) > (size_t)e->solverS.n * e->solverS.ld) return JAICOV_INVERT_FULL;
     return invert;
 }
 

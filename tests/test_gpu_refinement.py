@@ -165,3 +165,24 @@ def test_expanded_mode_falls_back_to_full_where_it_cannot_apply(oracle_mod):
     sd = np.sqrt(np.abs(np.diag(Qref)))
     assert (np.abs(Q - Qref) / np.outer(sd, sd)).max() < 1e-9
     eng.close()
+
+
+def test_expanded_mode_takes_the_literal_route_when_the_exterior_orientations_outnumber_its_workspace(oracle_mod):
+    """40 images of 8 points each on 12 object points: 240 EO unknowns against a reduced order of 52.  The expansion's F, T1, T2 do not fit
+    the reduced solver's workspace, so FULL_EXPANDED is served by the factorisation of the unreduced system -- same matrix."""
+    fp = scene.make_scene(40, 12, 8, dist=scene.DIST_FULL, weights="block", n_control=4, control_dense=True)
+    o = oracle_mod.Oracle(fp)
+    s2, U = fp.sigma2apriori, fp.n_unknowns
+    dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, True)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_FULL_EXPANDED)
+    eng.build(s2, 0.0)
+    assert eng.reduced_order() == U                       # the build assembled the unreduced system
+    dx = eng.solve(engine.INVERT_FULL_EXPANDED)
+    assert eng.cofactor_order() == U
+    np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
+    sd = np.sqrt(np.abs(np.diag(Qref)))
+    assert (np.abs(Q - Qref) / np.outer(sd, sd)).max() < 1e-8
+    eng.close()
