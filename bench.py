@@ -104,6 +104,15 @@ def cpu_baseline(fp, eng, sigma2):
                                          "iterations_per_s": 1.0 / sec["pass1_total"]}
         except Exception:
             pass
+    # the packed Bunch-Kaufman factorisation at the FULL order, measured on a host of this pool (EPYC 9575F, the model every GPU box
+    # of the pool has shown) by scripts/cfg4_exact.py on the device's own matrix: no extrapolation for the dominant CPU stage
+    log = os.path.join(ROOT, "profiles", "r03_cfg4_accuracy.log")
+    if fp.n_unknowns == 18014 and os.path.exists(log):
+        import re
+        found = dict((int(o), float(t)) for o, t in re.findall(r"dsptrf of order (\d+): (\d+) s", open(log).read()))
+        if found:
+            res["measured_dsptrf_on_pool_host_s"] = {"by_order": found, "threads_running": 2, "cores_each": 1,
+                                                     "source": "profiles/r03_cfg4_accuracy.log (scripts/cfg4_exact.py, two factorisations side by side)"}
     return res
 
 
