@@ -217,6 +217,8 @@ def config(name: str, **kw) -> FlatProblem:
         return make_scene(20, 200, 200, dist=DIST_RADIAL, weights="diag", n_control=4, **kw)
     if name == "cfg3":      # 100 x 1000, full interior set, 2x2 blocks
         return make_scene(100, 1000, 400, dist=DIST_FULL, weights="2x2", n_control=6, **kw)
+    if name == "cfg3_block":   # config 3's size with config 4's dense per-image dispersions (U = 3 614): the EO-reduced dataflow path at a mid size
+        return make_scene(100, 1000, 400, dist=DIST_FULL, weights="block", n_control=15, control_dense=True, **kw)
     if name in ("cfg4", "cfg5"):   # 500 x 5000, dense dispersion per image + dense 45x45 control block
         return make_scene(500, 5000, 500, dist=DIST_FULL, weights="block", n_control=15, control_dense=True, **kw)
     if name == "tiny":      # parity-test size: oracle finishes in milliseconds
