@@ -317,6 +317,9 @@ static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_
     for (int attempt = 0;; attempt++) {      // an abandoned dataflow factorisation (-9; orders >= 24 block columns) is repeated: d_D is untouched
         hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp, d_perm);
         HIPE(e, ds.potrf());
+        HIPE(e, ds.trtri());                 // enqueued behind the factorisation whatever its outcome: ONE host round trip per matrix
+        HIPE(e, ds.lauum());
+        hipLaunchKernelGGL(store_inv_kernel, dim3((m + 255) / 256, m), dim3(256), 0, e->stream, ds.Q, ds.ld, m, d_out);
         info = ds.fetch_info();
         if (info == -9 && attempt < 2) {
             ++e->flow_retries;
@@ -327,10 +330,6 @@ static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_
     }
     if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation of a dispersion matrix did not complete on the device (code " + std::to_string(info) + ")");
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)");
-    HIPE(e, ds.trtri());
-    HIPE(e, ds.lauum());
-    hipLaunchKernelGGL(store_inv_kernel, dim3((m + 255) / 256, m), dim3(256), 0, e->stream, ds.Q, ds.ld, m, d_out);
-    HIPE(e, hipStreamSynchronize(e->stream));
     return JAICOV_OK;
 }
 
