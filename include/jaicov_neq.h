@@ -317,8 +317,8 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
  * algorithmic flops of SURVEY 8(d)'s dense-group row, sum_g 2 m^2 (k+1) + m (k+1)(k+2).
  * With n >= 10, health counters of the dataflow factorisation since jaicov_neq_create (not reset): [6] factorisations that were
  * abandoned on the device (a bounded wait ran out) and repeated, [7] flags that only the slow-path poll found, [8] of those the
- * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == [9] == 0;
- * bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
+ * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == 0 ([7]..[9] are informational:
+ * the slow-path poll also finds flags that were simply set late); bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
  * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).                                     */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset);
