@@ -260,6 +260,332 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The two chains for ONE right-hand side, eight free-running waves per workgroup (round 3).
+//
+// What bounds the chains above is not the link (hop + block product + product with the inverse) but the STREAM: every
+// workgroup consumes the results in order, one 128 KB block of L per result, and the time of that iteration -- issue the
+// next block's loads, poll (the poll's s_waitcnt vmcnt(0) also waits for the loads just issued: loads return in order),
+// barrier, 64 FMAs per thread, copy the next block's registers into the current ones (which waits for them once more) -- is one
+// memory latency with ONE block in flight per CU: 3.4 us, and the workgroup of the longest column has 117 of them: 0.41 ms,
+// whatever the link costs (measured: removing 1 us from the link changed nothing; touching blocks ahead into L2 made it slower).
+// So:
+//  * every wave polls for itself -- backward: the 16 values that multiply its 16 rows of the block, broadcast by v_readlane;
+//    forward: each lane the two values of its two columns -- no staging through LDS and NO barrier in the loop: the eight waves
+//    run free of each other;
+//  * the poll for the NEXT result is issued BEFORE the refill of the buffer just used: loads return in order, so waiting for
+//    that poll (s_waitcnt vmcnt(16)) leaves the 16 refill loads in flight; only a poll that has to be repeated waits for them,
+//    and then the workgroup is ahead of the chain anyway;
+//  * two block buffers used in turn (loop unrolled by two, no copy); all loads and polls are unconditional (indices past the end
+//    re-read the last block / an already published result, whose product is discarded) so that the loop body is straight-line code
+//    and the compiler's s_waitcnt counts stay exact;
+//  * the LAST block of every stream, the only one on the chain's critical path, is multiplied into the diagonal inverse
+//    beforehand:   backward  x_k = W_k'(z_k - S) - P_k' x_{k+1},  P_k = L[k+1][k] W_k;
+//                  forward   z_k = W_k (b_k - S) - Ft_k' z_{k-1},  Ft_k = (W_k L[k][k-1])'
+//    (DenseSolver::premultiply(): two batched 128^3 MFMA GEMMs after the factorisation, ~20 us, shared by the three chains of a
+//    pass).  P_k / Ft_k has the shape of a streamed block and simply is the last block of the stream; u = W(..) is formed one
+//    link early, with inv(L_kk) in LDS.  When the predecessor's result appears every wave polls the 16 values it needs and ONE
+//    exchange through LDS + barrier joins the partial sums.
+// Same flag protocol (results preset to the all-ones pattern, relaxed agent-scope atomics), same progress argument (a workgroup
+// waits only for workgroups with a smaller index) and the same bounded spin as above.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ unsigned long long chain_poll(const unsigned long long *p, int spin) {
+    // every 1024th poll by a read-modify-write at agent scope (see backsolve_chain_kernel)
+    return (spin & 1023) == 1023 ? __hip_atomic_fetch_or(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// first poll (issued early, see above); chain_poll_finish() repeats it until the value is there
+__device__ __forceinline__ unsigned long long chain_poll_issue(const double *p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double chain_poll_finish(unsigned long long b, const double *p) {
+    int spin = 0;
+    while (b == BS_UNSET && ++spin < BS_SPIN_MAX) {
+        __builtin_amdgcn_s_sleep(2);
+        b = chain_poll(reinterpret_cast<const unsigned long long *>(p), spin);
+    }
+    return __longlong_as_double((long long)b);
+}
+// The wait on the chain's critical path.  `local`: the predecessor runs on this XCD (chain positions are dealt to the XCDs in
+// runs, see chain_position()), its write-through store has updated this XCD's L2, and a workgroup-scope load (sc0: misses the
+// CU's L1, hits the L2) sees it a memory round trip earlier than the agent-scope load (sc1) that a predecessor on another XCD
+// needs.  Every eighth poll is an agent-scope one all the same: should the hardware have placed the workgroups differently, this
+// costs time, not correctness (a stale L2 line can only hold the "not published" pattern: the L2 is invalidated at kernel start).
+__device__ __forceinline__ double chain_wait_tail(const double *src, bool local) {
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(src);
+    unsigned long long b = local ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+                                 : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int spin = 0;
+    while (b == BS_UNSET && ++spin < BS_SPIN_MAX) {
+        __builtin_amdgcn_s_sleep(1);
+        b = (local && (spin & 7) != 7) ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : chain_poll(p, spin);
+    }
+    return __longlong_as_double((long long)b);
+}
+// Chain position of a workgroup.  remap: positions are dealt to the XCDs in runs of R = ceil(nb / 8) (workgroup b runs on XCD
+// b % 8: position (b % 8) R + b / 8), so that all but seven links of the chain stay inside one XCD; the grid then has 8 R
+// workgroups, those past the end leave.  Only for grids that are resident as a whole (nb <= 256: the progress argument "a
+// workgroup waits only for workgroups dispatched before it" no longer holds across XCDs).
+__device__ __forceinline__ int chain_position(int nb, int remap, bool &local) {
+    const int b = blockIdx.x;
+    if (!remap) { local = false; return b; }
+    const int R = (nb + 7) >> 3;
+    local = (b >> 3) > 0;
+    return (b & 7) * R + (b >> 3);
+}
+__device__ __forceinline__ void chain_publish(double *dst, double v) {
+    unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (bits == BS_UNSET) bits = 0x7FF8000000000000ull;
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int CHAIN8_THREADS = 512;
+
+// block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Loads past the end of the stream are
+// issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1: a
+// poll that has to be repeated waits for the loads issued after it, and near the end of the stream that wait is on the chain's
+// critical path.
+#define CHAIN8_LOAD(buf, real, ptr_real, ptr_dummy)                                                                       \
+    {                                                                                                                      \
+        const char *bp = (real) ? (ptr_real) : (ptr_dummy);                                                                \
+        const long st = (real) ? ld * 8 : 0;                                                                               \
+        const unsigned vo = (real) ? voff : 0u;                                                                            \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)r * st + vo);   \
+    }
+
+__global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
+                                                                          const double *__restrict__ P, const double *__restrict__ Z, double *X,
+                                                                          int nb, int remap, const int *abort_word, long long *trace) {
+    __shared__ double red[8][128];
+    __shared__ double comb[4][128];
+    __shared__ double vv[128];
+    __shared__ double Wl[128 * 129 / 2];           // inv(L_kk), lower triangle packed by rows
+    if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int qd = __builtin_amdgcn_readfirstlane(tid >> 6);   // stream: rows 16*qd .. 16*qd+15, columns 2*lane, 2*lane+1
+    bool local;
+    const int pos = chain_position(nb, remap, local);
+    if (pos >= nb) return;
+    const int k = nb - 1 - pos;
+    const bool has_prev = k + 1 < nb;
+    const int n = has_prev ? nb - 2 - k : 0;       // streamed blocks: block i is L[nb-1-i][k]
+    const int di = tid & 127, h4 = tid >> 7;       // diagonal phase: output di, operand quarter h4
+    {   // inv(L_kk) -> LDS
+        const double *w = invd + (long)k * 16384 + (long)(32 * h4) * 128 + di;
+        double t[32];
+#pragma unroll
+        for (int r = 0; r < 32; r++) t[r] = w[(long)r * 128];
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            const int rr = 32 * h4 + r;
+            if (di <= rr) Wl[rr * (rr + 1) / 2 + di] = t[r];
+        }
+    }
+    double zk = 0.0;
+    if (tid < 128) zk = Z[k * 128 + tid];
+    __syncthreads();
+    const char *pk = reinterpret_cast<const char *>(P + (long)k * 16384 + (long)(16 * qd) * 128);
+    const char *lcol = reinterpret_cast<const char *>(L + (long)(16 * qd) * ld + k * 128);
+    const long bstep = 128 * ld * 8;               // bytes from one block row to the next
+    const unsigned voff = 16u * (unsigned)lane;
+    const double *xq = X + 16 * qd + (lane & 15);  // + 128 * block row: the 16 values of this wave
+    d2_t A[16], B[16];                             // two stream buffers
+    double acc0 = 0.0, acc1 = 0.0;
+#define CHAIN8_USE(buf, xv, keep)                                \
+    {                                                            \
+        double s0 = 0.0, s1 = 0.0;                               \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) {         \
+            const double xr = readlane_f64(xv, r);               \
+            s0 += buf[r].x * xr;                                 \
+            s1 += buf[r].y * xr;                                 \
+        }                                                        \
+        if (keep) { acc0 += s0; acc1 += s1; }                    \
+    }
+    // the first poll goes out ahead of the first loads, like every later one
+    const char *dummy = reinterpret_cast<const char *>(invd);
+    unsigned long long pa = chain_poll_issue(xq + (long)(nb - 1) * 128);
+    __builtin_amdgcn_sched_barrier(0);
+    CHAIN8_LOAD(A, 0 < n, lcol + (long)(nb - 1) * bstep, dummy);
+    CHAIN8_LOAD(B, 1 < n, lcol + (long)(nb - 2) * bstep, dummy);
+    // P_k is fetched behind the stream (its registers are the stream's until then); one dword per line now, so that it comes from the L2 then
+    const int tch0 = *reinterpret_cast<const int *>(P + (long)k * 16384 + 32 * tid), tch1 = *reinterpret_cast<const int *>(P + (long)k * 16384 + 32 * tid + 16);
+    for (int i = 0; i < n; i += 2) {
+        const int ja = nb - 1 - i;                                  // block row of A (i < n: real)
+        const int jb = i + 1 < n ? ja - 1 : ja;                     // of B; none: an already published result, product discarded
+        const int jn = i + 2 < n ? ja - 2 : ja;
+        const double xa = chain_poll_finish(pa, xq + (long)ja * 128);
+        CHAIN8_USE(A, xa, true);
+        const unsigned long long pb = chain_poll_issue(xq + (long)jb * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        CHAIN8_LOAD(A, i + 2 < n, lcol + (long)(ja - 2) * bstep, dummy);
+        const double xb = chain_poll_finish(pb, xq + (long)jb * 128);
+        CHAIN8_USE(B, xb, i + 1 < n);
+        pa = chain_poll_issue(xq + (long)jn * 128);
+        __builtin_amdgcn_sched_barrier(0);
+        CHAIN8_LOAD(B, i + 3 < n, lcol + (long)(ja - 3) * bstep, dummy);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) A[r] = *reinterpret_cast<const d2_t *>(pk + (long)r * 1024 + voff);      // P_k
+    // u = W_k'(z_k - S)
+    red[qd][2 * lane] = acc0;
+    red[qd][2 * lane + 1] = acc1;
+    __syncthreads();
+    if (tid < 128) {
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += red[q][tid];
+        vv[tid] = zk - s;
+    }
+    __syncthreads();
+    {
+        double out = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < 32; r++) {
+            const int rr = 32 * h4 + r;
+            out += (di <= rr ? Wl[rr * (rr + 1) / 2 + di] : 0.0) * vv[rr];
+        }
+        comb[h4][di] = out;
+    }
+    __syncthreads();
+    double u = 0.0;
+    if (tid < 128) u = (comb[0][tid] + comb[1][tid]) + (comb[2][tid] + comb[3][tid]);
+    if (has_prev) {
+        const double xv = chain_wait_tail(xq + (long)(k + 1) * 128, local);
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const double xr = readlane_f64(xv, r); p0 += A[r].x * xr; p1 += A[r].y * xr; }
+        red[qd][2 * lane] = p0;
+        red[qd][2 * lane + 1] = p1;
+        __syncthreads();
+        if (tid < 128) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) s += red[q][tid];
+            u -= s;
+        }
+    }
+    if (tid < 128) chain_publish(X + (long)k * 128 + tid, u);
+    if (tch0 + tch1 == 0x7fffff17) vv[0] = 1.0;                  // keeps the touches alive
+    if (trace && tid == 0) trace[pos] = wall_clock64();          // JAICOV_CHAIN_TRACE: when each link was published (100 MHz)
+#undef CHAIN8_USE
+}
+
+__global__ __launch_bounds__(CHAIN8_THREADS) void forwardsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
+                                                                             const double *__restrict__ Ft, const double *__restrict__ Bv, double *Z,
+                                                                             int nb, int remap, long long *trace) {
+    __shared__ double red[128][65];                // per-lane partial sums of the 128 rows; the tail's partial sums ([8][128]) afterwards
+    __shared__ double part[4][128];
+    __shared__ double comb[4][128];
+    __shared__ double vv[128];
+    __shared__ double Wl[128 * 129 / 2];           // inv(L_kk), lower triangle packed by columns: (row, c) at c * 128 - c (c - 1) / 2 + (row - c)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int qd = __builtin_amdgcn_readfirstlane(tid >> 6);   // stream: rows 16*qd .. 16*qd+15, columns 2*lane, 2*lane+1
+    bool local;
+    const int k = chain_position(nb, remap, local);
+    if (k >= nb) return;
+    const bool has_prev = k > 0;
+    const int n = has_prev ? k - 1 : 0;            // streamed blocks: block i is L[k][i]
+    const int di = tid & 127, h4 = tid >> 7;       // diagonal phase: output row di, columns 32*h4 .. 32*h4+31
+    {
+        const double *w = invd + (long)k * 16384 + (long)di * 128 + 32 * h4;     // row di of inv(L_kk)
+        d4_t t[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) t[c] = *reinterpret_cast<const d4_t *>(w + 4 * c);
+#pragma unroll
+        for (int c = 0; c < 32; c++) {
+            const int cc = 32 * h4 + c;
+            if (cc <= di) Wl[cc * 128 - cc * (cc - 1) / 2 + (di - cc)] = t[c >> 2][c & 3];
+        }
+    }
+    double bk = 0.0;
+    if (tid < 128) bk = Bv[k * 128 + tid];
+    __syncthreads();
+    const char *fk = reinterpret_cast<const char *>(Ft + (long)k * 16384 + (long)(16 * qd) * 128);
+    const char *lrow = reinterpret_cast<const char *>(L + (long)(k * 128 + 16 * qd) * ld);
+    const unsigned voff = 16u * (unsigned)lane;
+    const double *zq = Z + 2 * lane;               // + 128 * block: the two values of this lane's columns
+    d2_t A[16], B[16];
+    double acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0;
+#define CHAIN8_USE(buf, z0, z1, keep)                                                                    \
+    {                                                                                                    \
+        const double f0 = (keep) ? z0 : 0.0, f1 = (keep) ? z1 : 0.0;                                     \
+        _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = __builtin_fma(buf[r].y, f1, __builtin_fma(buf[r].x, f0, acc[r])); \
+    }
+    const char *dummy = reinterpret_cast<const char *>(invd);
+    unsigned long long pa0 = chain_poll_issue(zq), pa1 = chain_poll_issue(zq + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    CHAIN8_LOAD(A, 0 < n, lrow, dummy);
+    CHAIN8_LOAD(B, 1 < n, lrow + 1024, dummy);
+    const int tch0 = *reinterpret_cast<const int *>(Ft + (long)k * 16384 + 32 * tid), tch1 = *reinterpret_cast<const int *>(Ft + (long)k * 16384 + 32 * tid + 16);
+    for (int i = 0; i < n; i += 2) {
+        const int jb = i + 1 < n ? i + 1 : i;                       // no such block: an already published result, product discarded
+        const int jn = i + 2 < n ? i + 2 : i;
+        const double za0 = chain_poll_finish(pa0, zq + (long)i * 128), za1 = chain_poll_finish(pa1, zq + (long)i * 128 + 1);
+        CHAIN8_USE(A, za0, za1, true);
+        const unsigned long long pb0 = chain_poll_issue(zq + (long)jb * 128), pb1 = chain_poll_issue(zq + (long)jb * 128 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        CHAIN8_LOAD(A, i + 2 < n, lrow + (long)(i + 2) * 1024, dummy);
+        const double zb0 = chain_poll_finish(pb0, zq + (long)jb * 128), zb1 = chain_poll_finish(pb1, zq + (long)jb * 128 + 1);
+        CHAIN8_USE(B, zb0, zb1, i + 1 < n);
+        pa0 = chain_poll_issue(zq + (long)jn * 128);
+        pa1 = chain_poll_issue(zq + (long)jn * 128 + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        CHAIN8_LOAD(B, i + 3 < n, lrow + (long)(i + 3) * 1024, dummy);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) A[r] = *reinterpret_cast<const d2_t *>(fk + (long)r * 1024 + voff);      // Ft_k
+#pragma unroll
+    for (int r = 0; r < 16; r++) red[16 * qd + r][lane] = acc[r];
+    __syncthreads();
+    {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < 16; c++) s += red[di][16 * h4 + c];
+        part[h4][di] = s;
+    }
+    __syncthreads();
+    if (tid < 128) vv[tid] = bk - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
+    __syncthreads();
+    {   // u = W_k (b_k - S)
+        double out = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < 32; c++) {
+            const int cc = 32 * h4 + c;
+            out += (cc <= di ? Wl[cc * 128 - cc * (cc - 1) / 2 + (di - cc)] : 0.0) * vv[cc];
+        }
+        comb[h4][di] = out;
+    }
+    __syncthreads();
+    double u = 0.0;
+    if (tid < 128) u = (comb[0][tid] + comb[1][tid]) + (comb[2][tid] + comb[3][tid]);
+    if (has_prev) {
+        double *red2 = &red[0][0];                 // [8][128]; every read of red[][] is two barriers back
+        const double zv = chain_wait_tail(Z + (long)(k - 1) * 128 + 16 * qd + (lane & 15), local);
+        double p0 = 0.0, p1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const double zr = readlane_f64(zv, r); p0 += A[r].x * zr; p1 += A[r].y * zr; }
+        red2[qd * 128 + 2 * lane] = p0;
+        red2[qd * 128 + 2 * lane + 1] = p1;
+        __syncthreads();
+        if (tid < 128) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) s += red2[q * 128 + tid];
+            u -= s;
+        }
+    }
+    if (tid < 128) chain_publish(Z + (long)k * 128 + tid, u);
+    if (tch0 + tch1 == 0x7fffff17) vv[0] = 1.0;                  // keeps the touches alive
+    if (trace && tid == 0) trace[k] = wall_clock64();
+#undef CHAIN8_USE
+}
+#undef CHAIN8_LOAD
+
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
     const int k = blockIdx.x;
     for (int idx = threadIdx.x; idx < 128 * 128; idx += blockDim.x) {
@@ -299,6 +625,9 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMalloc(&L, sq));
     HIPCHK(hipMalloc(&invd, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * 2 * 16384 * sizeof(double)));
+    HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * 2 * 16384 * sizeof(double)));
+    pm_ready = false;
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
 
     // Which factorisation: both are bound by a chain of one link per block column while the order is small (dataflow: the
@@ -361,7 +690,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
 void DenseSolver::release() {
     if (!owns) return;
     flow_release();
-    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q);
+    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(pm);
     hipFree(tile_map_store);
     tile_map_store = nullptr;
     for (auto &kv : trtri_maps) hipFree(kv.second);
@@ -376,6 +705,7 @@ void DenseSolver::release() {
     if (dstream) hipStreamDestroy(dstream);
     pstream = ustream = dstream = nullptr;
     L = invd = W = Q = nullptr;
+    pm = nullptr; pm_ready = false;
     d_info = nullptr;
     owns = false;
 }
@@ -478,6 +808,7 @@ int DenseSolver::first_panel_cols() const {
 }
 
 hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
+    pm_ready = false;
     if (flow_ready) return potrf_flow(all_ready);
     return potrf_streams(first_ready, all_ready);
 }
@@ -633,12 +964,47 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
     return hipGetLastError();
 }
 
+// chain positions dealt to the XCDs in runs (chain_position()): only when the whole grid is resident at once
+static int chain_remap(int nb) {
+    static const bool off = getenv("JAICOV_CHAIN_NO_REMAP") != nullptr;
+    return (!off && nb >= 16 && nb <= 256) ? 1 : 0;
+}
+
+// P_k = L[k+1][k] W_k (k < nb-1) and Ft_k = (W_k L[k][k-1])' (k > 0) of the factor at hand, once per factorisation
+// (backsolve_chain8_kernel / forwardsolve_chain8_kernel).  pm = [P_0 .. P_{nb-1}][Ft_0 .. Ft_{nb-1}], 128 x 128 row-major each.
+hipError_t DenseSolver::premultiply() {
+    if (pm_ready || !pm) return hipSuccess;
+    const int nb = nfact / 128;
+    if (nb > 1) {
+        const long bstride = 128 * (ld + 1);
+        GemmArgs p{};
+        p.A = L + 128 * ld; p.lda = ld; p.strideA = bstride;                   // L[k+1][k]   (KC)
+        p.B = invd; p.ldb = 128; p.strideB = 16384;                           // W_k (k, j) row-major (XC)
+        p.C = pm; p.ldc = 128; p.strideC = 16384;
+        p.M = p.N = p.K = 128; p.alpha = 1.0; p.beta = 0.0; p.kmode = KMODE_FULL;
+        HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, p, nb - 1, 0));
+        GemmArgs f{};                                                          // Ft_k = L[k][k-1]' W_k', k >= 1
+        f.A = L + 128 * ld; f.lda = ld; f.strideA = bstride;                   // L[k][k-1] read transposed (XC)
+        f.B = invd + 16384; f.ldb = 128; f.strideB = 16384;                   // W_k' (k, j) = W_k[j][k] (KC)
+        f.C = pm + (size_t)(nb + 1) * 16384; f.ldc = 128; f.strideC = 16384;
+        f.M = f.N = f.K = 128; f.alpha = 1.0; f.beta = 0.0; f.kmode = KMODE_FULL;
+        HIPCHK(gemm_f64(stream, LAY_XC, LAY_KC, f, nb - 1, 0));
+    }
+    pm_ready = true;
+    return hipGetLastError();
+}
+
 hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     if (!aug || nrhs < 1 || nrhs > DENSE_MAX_RHS) return hipErrorInvalidValue;
     const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nrhs * xs * sizeof(double), stream));   // "not yet published"
     const int *ab = flow_ready ? flow_flags + 1 : nullptr;      // cholflow.hip FLOW_ABORT
-    if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
+    static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;      // the chains without pre-multiplied last blocks
+    if (nrhs <= 1 && pm && !plain) {
+        HIPCHK(premultiply());
+        const int remap = chain_remap(nb);
+        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(remap ? 8 * ((nb + 7) / 8) : nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, rhs_row(0), X, nb, remap, ab, (long long *)nullptr);
+    } else if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else hipLaunchKernelGGL(backsolve_chain_kernel<8>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
@@ -651,6 +1017,29 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
     const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(tmp, 0xFF, (size_t)nfact * sizeof(double), stream));
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nfact * sizeof(double), stream));
+    static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;
+    if (pm && !plain) {
+        HIPCHK(premultiply());
+        const int remap = chain_remap(nb);
+        const dim3 grid(remap ? 8 * ((nb + 7) / 8) : nb);
+        static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the two chains on stderr
+        long long *tr = nullptr;
+        if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)2 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)2 * nb * sizeof(long long), stream)); }
+        hipLaunchKernelGGL(forwardsolve_chain8_kernel, grid, dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm + (size_t)nb * 16384, b, tmp, nb, remap, tr);
+        hipLaunchKernelGGL(backsolve_chain8_kernel, grid, dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, tmp, X, nb, remap, (const int *)nullptr, tr ? tr + nb : nullptr);
+        if (tracing) {
+            std::vector<long long> h((size_t)2 * nb);
+            HIPCHK(hipMemcpyAsync(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            hipFree(tr);
+            for (int c = 0; c < 2; c++) {
+                fprintf(stderr, "[jaicov chain trace] %s, nb %d, link times in 10 ns:", c ? "backward" : "forward", nb);
+                for (int q = 1; q < nb; q++) fprintf(stderr, " %lld", h[(size_t)c * nb + q] - h[(size_t)c * nb + q - 1]);
+                fprintf(stderr, "\n");
+            }
+        }
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
     hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, tmp, (long)nfact, X, (long)nfact, nb, 1, (const int *)nullptr);
     return hipGetLastError();
