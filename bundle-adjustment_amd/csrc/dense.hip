@@ -261,33 +261,41 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// The two chains for ONE right-hand side, eight free-running waves per workgroup (round 3).
+// The backward chain for ONE right-hand side: a polling wave and seven streaming waves per workgroup (round 3).
 //
-// What bounds the chains above is not the link (hop + block product + product with the inverse) but the STREAM: every
-// workgroup consumes the results in order, one 128 KB block of L per result, and the time of that iteration -- issue the
-// next block's loads, poll (the poll's s_waitcnt vmcnt(0) also waits for the loads just issued: loads return in order),
-// barrier, 64 FMAs per thread, copy the next block's registers into the current ones (which waits for them once more) -- is one
-// memory latency with ONE block in flight per CU: 3.4 us, and the workgroup of the longest column has 117 of them: 0.41 ms,
-// whatever the link costs (measured: removing 1 us from the link changed nothing; touching blocks ahead into L2 made it slower).
-// So:
-//  * every wave polls for itself -- backward: the 16 values that multiply its 16 rows of the block, broadcast by v_readlane;
-//    forward: each lane the two values of its two columns -- no staging through LDS and NO barrier in the loop: the eight waves
-//    run free of each other;
-//  * the poll for the NEXT result is issued BEFORE the refill of the buffer just used: loads return in order, so waiting for
-//    that poll (s_waitcnt vmcnt(16)) leaves the 16 refill loads in flight; only a poll that has to be repeated waits for them,
-//    and then the workgroup is ahead of the chain anyway;
-//  * two block buffers used in turn (loop unrolled by two, no copy); all loads and polls are unconditional (indices past the end
-//    re-read the last block / an already published result, whose product is discarded) so that the loop body is straight-line code
-//    and the compiler's s_waitcnt counts stay exact;
-//  * the LAST block of every stream, the only one on the chain's critical path, is multiplied into the diagonal inverse
-//    beforehand:   backward  x_k = W_k'(z_k - S) - P_k' x_{k+1},  P_k = L[k+1][k] W_k;
-//                  forward   z_k = W_k (b_k - S) - Ft_k' z_{k-1},  Ft_k = (W_k L[k][k-1])'
-//    (DenseSolver::premultiply(): two batched 128^3 MFMA GEMMs after the factorisation, ~20 us, shared by the three chains of a
-//    pass).  P_k / Ft_k has the shape of a streamed block and simply is the last block of the stream; u = W(..) is formed one
-//    link early, with inv(L_kk) in LDS.  When the predecessor's result appears every wave polls the 16 values it needs and ONE
-//    exchange through LDS + barrier joins the partial sums.
-// Same flag protocol (results preset to the all-ones pattern, relaxed agent-scope atomics), same progress argument (a workgroup
-// waits only for workgroups with a smaller index) and the same bounded spin as above.
+// A link of the chain above takes 3.4 us although the hop itself -- agent-scope store in one workgroup, agent-scope load in
+// another -- takes 0.53 us inside an XCD and 0.59 us across XCDs (scripts/micro/hop_latency.hip; the same test shows that a
+// workgroup-scope load (sc0) is served by the CU's L1 and NEVER sees another workgroup's store, so there is no cheaper poll for
+// neighbours on one XCD).  The rest is how a workgroup waits and what it still has to do once the last result it depends on is
+// there (JAICOV_CHAIN_TRACE prints the link times and the phases of a workgroup):
+//  * every workgroup consumes the results in order, one 128 KB block of L per result: it issues the next block's loads, polls
+//    (the poll's s_waitcnt vmcnt(0) also waits for the loads just issued: loads return in order), meets at a barrier, does 64
+//    FMAs per thread, copies the next block's registers into the current ones (which waits for them once more).  Polls issued
+//    ahead of the loads do not help: every REPEATED poll still queues behind them;
+//  * behind its last block it reduces the partial sums, multiplies with inv(L_kk), and only then publishes: four barriers,
+//    each of which (__syncthreads) also waits for every global load in flight.
+// Here the two kinds of waiting are separated and most of the work behind the last block is moved in front of it:
+//  * wave 0 does nothing but poll: it has no other memory operation in flight, runs up to CH_RD results ahead of the stream and
+//    hands them over through a ring in LDS (values + a sequence word per slot; a count of the waves that are done with a slot
+//    lets it be reused);
+//  * waves 1..7 stream the blocks (18 or 19 rows each), two buffers used in turn, every refill issued right behind the last use
+//    of its buffer.  They wait for results by spinning on the sequence word in LDS -- lgkmcnt, not vmcnt: their block loads stay
+//    in flight -- and for a block with the exact s_waitcnt vmcnt the compiler derives from straight-line code (all loads are
+//    unconditional; past the end of the stream they re-read one 16-byte piece that sits in the L1).  No workgroup barrier in
+//    the loop;
+//  * the LAST TWO blocks of every stream are multiplied into the diagonal inverse beforehand,
+//        x_k = W_k'(z_k - S) - P1_k' x_{k+1} - P2_k' x_{k+2},   P1_k = L[k+1][k] W_k,  P2_k = L[k+2][k] W_k
+//    (DenseSolver::premultiply(): two batched 128^3 MFMA GEMMs after the factorisation), so that u = W_k'(z_k - S) -- the
+//    reduction, three barriers, the product with inv(L_kk) from LDS -- is formed two links early.  When x_{k+2} and x_{k+1}
+//    appear, every streaming wave polls the values that multiply its rows itself (nothing else is in flight by then; the first
+//    polls go out in front of the u-phase), broadcasts them with v_readlane, and ONE exchange through LDS + barrier joins the
+//    partial sums.  The barriers behind the stream order LDS traffic only (chain_lds_barrier()).
+// Same flag protocol towards the other workgroups (results preset to the all-ones pattern, relaxed agent-scope atomics), same
+// progress argument (a workgroup waits only for workgroups with a smaller index) and the same bounded spin as above.
+// What it gives at config 4 (118 links): 0.41 -> 0.345 ms.  The links now cost ~2.9 us on average: the path from "x_{k+3} published"
+// to "x_k published" inside one workgroup is still ~9 us (trace: the streaming waves finish the stream up to 3.5 us apart, 1.9 us
+// for the product with inv(L_kk)), three links' worth.  The forward chain keeps its first form: this layout needs 19 row sums per
+// lane there and spills.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -298,44 +306,18 @@ __device__ __forceinline__ unsigned long long chain_poll(const unsigned long lon
     return (spin & 1023) == 1023 ? __hip_atomic_fetch_or(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                  : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// first poll (issued early, see above); chain_poll_finish() repeats it until the value is there
-__device__ __forceinline__ unsigned long long chain_poll_issue(const double *p) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// the waits on the chain's critical path: first poll (issued early), then repeated until the value is there
+__device__ __forceinline__ unsigned long long chain_tail_issue(const double *src) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double chain_poll_finish(unsigned long long b, const double *p) {
-    int spin = 0;
-    while (b == BS_UNSET && ++spin < BS_SPIN_MAX) {
-        __builtin_amdgcn_s_sleep(2);
-        b = chain_poll(reinterpret_cast<const unsigned long long *>(p), spin);
-    }
-    return __longlong_as_double((long long)b);
-}
-// The wait on the chain's critical path.  `local`: the predecessor runs on this XCD (chain positions are dealt to the XCDs in
-// runs, see chain_position()), its write-through store has updated this XCD's L2, and a workgroup-scope load (sc0: misses the
-// CU's L1, hits the L2) sees it a memory round trip earlier than the agent-scope load (sc1) that a predecessor on another XCD
-// needs.  Every eighth poll is an agent-scope one all the same: should the hardware have placed the workgroups differently, this
-// costs time, not correctness (a stale L2 line can only hold the "not published" pattern: the L2 is invalidated at kernel start).
-__device__ __forceinline__ double chain_wait_tail(const double *src, bool local) {
+__device__ __forceinline__ double chain_tail_finish(unsigned long long b, const double *src) {
     const unsigned long long *p = reinterpret_cast<const unsigned long long *>(src);
-    unsigned long long b = local ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
-                                 : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int spin = 0;
     while (b == BS_UNSET && ++spin < BS_SPIN_MAX) {
         __builtin_amdgcn_s_sleep(1);
-        b = (local && (spin & 7) != 7) ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : chain_poll(p, spin);
+        b = chain_poll(p, spin);
     }
     return __longlong_as_double((long long)b);
-}
-// Chain position of a workgroup.  remap: positions are dealt to the XCDs in runs of R = ceil(nb / 8) (workgroup b runs on XCD
-// b % 8: position (b % 8) R + b / 8), so that all but seven links of the chain stay inside one XCD; the grid then has 8 R
-// workgroups, those past the end leave.  Only for grids that are resident as a whole (nb <= 256: the progress argument "a
-// workgroup waits only for workgroups dispatched before it" no longer holds across XCDs).
-__device__ __forceinline__ int chain_position(int nb, int remap, bool &local) {
-    const int b = blockIdx.x;
-    if (!remap) { local = false; return b; }
-    const int R = (nb + 7) >> 3;
-    local = (b >> 3) > 0;
-    return (b & 7) * R + (b >> 3);
 }
 __device__ __forceinline__ void chain_publish(double *dst, double v) {
     unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -343,36 +325,118 @@ __device__ __forceinline__ void chain_publish(double *dst, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr int CHAIN8_THREADS = 512;
+constexpr int CH_RD = 8;              // slots of the ring between the polling wave and the streaming waves
+constexpr int CH_SW = 7;              // streaming waves
+constexpr int CH_ROWS = 19;           // rows of a block per streaming wave: waves 1..5 take 18, waves 6 and 7 take 19
+struct ChainRing {
+    double xs[CH_RD + 1][128];        // published results, in the order of the stream; slot CH_RD: zeros (a step without a block)
+    int ready[CH_RD];                 // 1 + index of the stream entry the slot holds
+    int consumed[CH_RD];              // streaming waves that are done with the slot, counted over all its uses
+};
+__device__ __forceinline__ void chain_ring_init(ChainRing &rg, int tid) {
+    if (tid < CH_RD) { rg.ready[tid] = 0; rg.consumed[tid] = 0; }
+    if (tid < 128) rg.xs[CH_RD][tid] = 0.0;
+}
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight (s_waitcnt
+// vmcnt(0)): behind the stream those are the two pre-multiplied blocks and the first polls for the predecessors' results, which
+// the u-phase does not need -- its three barriers cost 7 us that way (JAICOV_CHAIN_TRACE), on the chain's critical path.
+__device__ __forceinline__ void chain_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// one dword of every 128-byte line of two 128 x 128 blocks, by one wave (pulls them into this XCD's L2)
+__device__ __forceinline__ int chain_touch2(const double *a, const double *b, int lane) {
+    int t = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) t += *reinterpret_cast<const int *>(a + 16 * (64 * q + lane)) + *reinterpret_cast<const int *>(b + 16 * (64 * q + lane));
+    return t;
+}
+// the polling wave: entry i of the stream = the 128 values at src
+__device__ __forceinline__ void chain_ring_put(ChainRing &rg, int i, const double *src, int lane) {
+    const int slot = i & (CH_RD - 1);
+    if (i >= CH_RD) {       // every streaming wave is done with what the slot held
+        const int need = CH_SW * (i / CH_RD);
+        while (__hip_atomic_load(&rg.consumed[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+    }
+    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(src) + lane;
+    unsigned long long b0, b1;
+    int spin = 0;
+    do {
+        b0 = chain_poll(p, spin);
+        b1 = chain_poll(p + 64, spin);
+        if (b0 == BS_UNSET || b1 == BS_UNSET) __builtin_amdgcn_s_sleep(1);
+    } while ((b0 == BS_UNSET || b1 == BS_UNSET) && ++spin < BS_SPIN_MAX);
+    rg.xs[slot][lane] = __longlong_as_double((long long)b0);
+    rg.xs[slot][lane + 64] = __longlong_as_double((long long)b1);
+    __hip_atomic_store(&rg.ready[slot], i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // one wave: every lane writes the same word
+}
+// a streaming wave: waits for entry i, returns its slot
+__device__ __forceinline__ int chain_ring_get(ChainRing &rg, int i) {
+    const int slot = i & (CH_RD - 1);
+    int spin = 0;
+    while (__hip_atomic_load(&rg.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != i + 1 && ++spin < BS_SPIN_MAX) __builtin_amdgcn_s_sleep(0);
+    return slot;
+}
+__device__ __forceinline__ void chain_ring_done(ChainRing &rg, int slot, int lane) {
+    if (lane == 0) __hip_atomic_fetch_add(&rg.consumed[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
-// block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Loads past the end of the stream are
-// issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1: a
-// poll that has to be repeated waits for the loads issued after it, and near the end of the stream that wait is on the chain's
-// critical path.
+// block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Row r of a wave's share is row
+// min(r, nrows - 1) (waves with 18 rows read their last row twice, its product is dropped).  Loads past the end of the stream are
+// issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1.
 #define CHAIN8_LOAD(buf, real, ptr_real, ptr_dummy)                                                                       \
     {                                                                                                                      \
         const char *bp = (real) ? (ptr_real) : (ptr_dummy);                                                                \
         const long st = (real) ? ld * 8 : 0;                                                                               \
         const unsigned vo = (real) ? voff : 0u;                                                                            \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)r * st + vo);   \
+        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
+            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * st + vo);                        \
+    }
+
+// the pre-multiplied block `src` (128 x 128, row-major) of a streaming wave: rows r0.., columns 2*lane, 2*lane+1
+#define CHAIN8_LOAD_PM(buf, src)                                                                                           \
+    {                                                                                                                      \
+        const char *bp = reinterpret_cast<const char *>((src) + (long)r0 * 128);                                           \
+        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
+            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * 1024 + voff);                    \
+    }
+// p0, p1 += buf' v for the rows of this wave, v = the 128 values at src (published by a predecessor); lanes 0..18 poll.  The first
+// poll (q) went out in front of the u-phase (CHAIN8_TAIL_ISSUE): a memory round trip is ~1.5 us, three of them one after the other
+// on the path x_{k+3} -> x_k were most of what that path cost
+#define CHAIN8_TAIL_SRC(src) ((src) + r0 + ((lane < CH_ROWS ? lane : CH_ROWS - 1) < nrows ? (lane < CH_ROWS ? lane : CH_ROWS - 1) : last_row))
+#define CHAIN8_TAIL(buf, q, src)                                                                                           \
+    {                                                                                                                      \
+        const double xw = chain_tail_finish(q, CHAIN8_TAIL_SRC(src));                                                      \
+        const double xv = (lane == 18 && nrows == 18) ? 0.0 : xw;                                                          \
+        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++) {                                                              \
+            const double xr = readlane_f64(xv, r);                                                                         \
+            p0 += buf[r].x * xr;                                                                                           \
+            p1 += buf[r].y * xr;                                                                                           \
+        }                                                                                                                  \
     }
 
 __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
-                                                                          const double *__restrict__ P, const double *__restrict__ Z, double *X,
-                                                                          int nb, int remap, const int *abort_word, long long *trace) {
+                                                                          const double *__restrict__ P1, const double *__restrict__ P2,
+                                                                          const double *__restrict__ Z, double *X, int nb,
+                                                                          const int *abort_word, long long *trace) {
     __shared__ double red[8][128];
     __shared__ double comb[4][128];
     __shared__ double vv[128];
     __shared__ double Wl[128 * 129 / 2];           // inv(L_kk), lower triangle packed by rows
+    __shared__ ChainRing ring;
     if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int qd = __builtin_amdgcn_readfirstlane(tid >> 6);   // stream: rows 16*qd .. 16*qd+15, columns 2*lane, 2*lane+1
-    bool local;
-    const int pos = chain_position(nb, remap, local);
-    if (pos >= nb) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pos = blockIdx.x;                    // position in the chain
     const int k = nb - 1 - pos;
-    const bool has_prev = k + 1 < nb;
-    const int n = has_prev ? nb - 2 - k : 0;       // streamed blocks: block i is L[nb-1-i][k]
+    const bool has1 = k + 1 < nb, has2 = k + 2 < nb;           // x_{k+1} through P1_k, x_{k+2} through P2_k
+    const int n = has2 ? nb - 3 - k : 0;           // streamed blocks: entry i is L[nb-1-i][k] with x_{nb-1-i}
     const int di = tid & 127, h4 = tid >> 7;       // diagonal phase: output di, operand quarter h4
+    // streaming waves 1..7: rows r0 .. r0 + nrows - 1, columns 2*lane, 2*lane+1
+    const int nrows = wave <= 5 ? 18 : 19;
+    const int last_row = nrows - 1;                // buffer entry 18 of a wave with 18 rows repeats row 17 (its product is dropped)
+    const int r0 = wave == 0 ? 0 : (wave <= 5 ? 18 * (wave - 1) : 90 + 19 * (wave - 6));
+#define CHAIN8_STAMP(q) if (trace && tid == 64) trace[nb + 8 * pos + (q)] = wall_clock64();
+#define CHAIN8_STAMP_T(q, t) if (trace && tid == (t)) trace[nb + 8 * pos + (q)] = wall_clock64();
+    CHAIN8_STAMP(0);
+    chain_ring_init(ring, tid);
     {   // inv(L_kk) -> LDS
         const double *w = invd + (long)k * 16384 + (long)(32 * h4) * 128 + di;
         double t[32];
@@ -387,59 +451,75 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     double zk = 0.0;
     if (tid < 128) zk = Z[k * 128 + tid];
     __syncthreads();
-    const char *pk = reinterpret_cast<const char *>(P + (long)k * 16384 + (long)(16 * qd) * 128);
-    const char *lcol = reinterpret_cast<const char *>(L + (long)(16 * qd) * ld + k * 128);
+    const char *lcol = reinterpret_cast<const char *>(L + (long)r0 * ld + k * 128);
     const long bstep = 128 * ld * 8;               // bytes from one block row to the next
     const unsigned voff = 16u * (unsigned)lane;
-    const double *xq = X + 16 * qd + (lane & 15);  // + 128 * block row: the 16 values of this wave
-    d2_t A[16], B[16];                             // two stream buffers
-    double acc0 = 0.0, acc1 = 0.0;
-#define CHAIN8_USE(buf, xv, keep)                                \
-    {                                                            \
-        double s0 = 0.0, s1 = 0.0;                               \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) {         \
-            const double xr = readlane_f64(xv, r);               \
-            s0 += buf[r].x * xr;                                 \
-            s1 += buf[r].y * xr;                                 \
-        }                                                        \
-        if (keep) { acc0 += s0; acc1 += s1; }                    \
-    }
-    // the first poll goes out ahead of the first loads, like every later one
     const char *dummy = reinterpret_cast<const char *>(invd);
-    unsigned long long pa = chain_poll_issue(xq + (long)(nb - 1) * 128);
-    __builtin_amdgcn_sched_barrier(0);
-    CHAIN8_LOAD(A, 0 < n, lcol + (long)(nb - 1) * bstep, dummy);
-    CHAIN8_LOAD(B, 1 < n, lcol + (long)(nb - 2) * bstep, dummy);
-    // P_k is fetched behind the stream (its registers are the stream's until then); one dword per line now, so that it comes from the L2 then
-    const int tch0 = *reinterpret_cast<const int *>(P + (long)k * 16384 + 32 * tid), tch1 = *reinterpret_cast<const int *>(P + (long)k * 16384 + 32 * tid + 16);
-    for (int i = 0; i < n; i += 2) {
-        const int ja = nb - 1 - i;                                  // block row of A (i < n: real)
-        const int jb = i + 1 < n ? ja - 1 : ja;                     // of B; none: an already published result, product discarded
-        const int jn = i + 2 < n ? ja - 2 : ja;
-        const double xa = chain_poll_finish(pa, xq + (long)ja * 128);
-        CHAIN8_USE(A, xa, true);
-        const unsigned long long pb = chain_poll_issue(xq + (long)jb * 128);
-        __builtin_amdgcn_sched_barrier(0);
-        CHAIN8_LOAD(A, i + 2 < n, lcol + (long)(ja - 2) * bstep, dummy);
-        const double xb = chain_poll_finish(pb, xq + (long)jb * 128);
-        CHAIN8_USE(B, xb, i + 1 < n);
-        pa = chain_poll_issue(xq + (long)jn * 128);
-        __builtin_amdgcn_sched_barrier(0);
-        CHAIN8_LOAD(B, i + 3 < n, lcol + (long)(ja - 3) * bstep, dummy);
+    d2_t A[CH_ROWS], B[CH_ROWS];                   // two stream buffers; P1_k and P2_k behind the stream
+    double acc0 = 0.0, acc1 = 0.0;
+    unsigned long long q1 = BS_UNSET, q2 = BS_UNSET;
+    // P1_k, P2_k are fetched behind the stream (their registers are the stream's until then); one dword per line now, so that they
+    // come from the L2 then
+    const double *p1k = P1 + (long)k * 16384, *p2k = P2 + (long)k * 16384;
+    const int tch = *reinterpret_cast<const int *>(p1k + 32 * tid) + *reinterpret_cast<const int *>(p1k + 32 * tid + 16) +
+                    *reinterpret_cast<const int *>(p2k + 32 * tid) + *reinterpret_cast<const int *>(p2k + 32 * tid + 16);
+    if (wave == 0) {
+        int tsum = 0;
+        for (int i = 0; i < n; i++) {
+            if (i == n - 5) tsum = chain_touch2(p1k, p2k, lane);      // P1_k, P2_k back into the L2 shortly before they are fetched
+            chain_ring_put(ring, i, X + (long)(nb - 1 - i) * 128, lane);
+        }
+        if (tsum == 0x7fffff17) vv[1] = 1.0;
+        CHAIN8_STAMP_T(6, 0);
+    } else {
+        const int xlane = r0 + (lane < 18 ? lane : last_row);
+        const bool xdrop = lane == 18 && nrows == 18;
+#define CHAIN8_USE(buf, slot)                                                        \
+    {                                                                                \
+        const double xl = ring.xs[slot][xlane];     /* one LDS read per lane, then scalar broadcasts */ \
+        const double xv = xdrop ? 0.0 : xl;         /* entry 18 of a wave with 18 rows */ \
+        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++) {                        \
+            const double xr = readlane_f64(xv, r);                                   \
+            acc0 += buf[r].x * xr;                                                   \
+            acc1 += buf[r].y * xr;                                                   \
+        }                                                                            \
     }
-#pragma unroll
-    for (int r = 0; r < 16; r++) A[r] = *reinterpret_cast<const d2_t *>(pk + (long)r * 1024 + voff);      // P_k
-    // u = W_k'(z_k - S)
-    red[qd][2 * lane] = acc0;
-    red[qd][2 * lane + 1] = acc1;
-    __syncthreads();
+        CHAIN8_LOAD(A, 0 < n, lcol + (long)(nb - 1) * bstep, dummy);
+        CHAIN8_LOAD(B, 1 < n, lcol + (long)(nb - 2) * bstep, dummy);
+        for (int i = 0; i < n; i += 2) {
+            const int ja = nb - 1 - i;                                  // block row of A
+            const int sa = chain_ring_get(ring, i);
+            CHAIN8_USE(A, sa);
+            chain_ring_done(ring, sa, lane);
+            CHAIN8_LOAD(A, i + 2 < n, lcol + (long)(ja - 2) * bstep, dummy);
+            const bool realb = i + 1 < n;
+            int sb = CH_RD;                                             // no such block: zeros
+            if (realb) sb = chain_ring_get(ring, i + 1);
+            CHAIN8_USE(B, sb);
+            if (realb) chain_ring_done(ring, sb, lane);
+            CHAIN8_LOAD(B, i + 3 < n, lcol + (long)(ja - 3) * bstep, dummy);
+        }
+#undef CHAIN8_USE
+        CHAIN8_STAMP(1);
+        CHAIN8_STAMP_T(7, 448);
+        CHAIN8_LOAD_PM(A, p1k);
+        CHAIN8_LOAD_PM(B, p2k);
+        q2 = chain_tail_issue(CHAIN8_TAIL_SRC(X + (long)(has2 ? k + 2 : k) * 128));     // in flight during the u-phase
+        q1 = chain_tail_issue(CHAIN8_TAIL_SRC(X + (long)(has1 ? k + 1 : k) * 128));
+        red[wave][2 * lane] = acc0;
+        red[wave][2 * lane + 1] = acc1;
+    }
+    // u = W_k'(z_k - S), S over the streamed blocks
+    chain_lds_barrier();
+    CHAIN8_STAMP(2);
     if (tid < 128) {
         double s = 0.0;
 #pragma unroll
-        for (int q = 0; q < 8; q++) s += red[q][tid];
+        for (int q = 1; q <= CH_SW; q++) s += red[q][tid];
         vv[tid] = zk - s;
     }
-    __syncthreads();
+    chain_lds_barrier();
+    CHAIN8_STAMP(3);
     {
         double out = 0.0;
 #pragma unroll 8
@@ -449,141 +529,37 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
         }
         comb[h4][di] = out;
     }
-    __syncthreads();
+    chain_lds_barrier();
     double u = 0.0;
     if (tid < 128) u = (comb[0][tid] + comb[1][tid]) + (comb[2][tid] + comb[3][tid]);
-    if (has_prev) {
-        const double xv = chain_wait_tail(xq + (long)(k + 1) * 128, local);
-        double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const double xr = readlane_f64(xv, r); p0 += A[r].x * xr; p1 += A[r].y * xr; }
-        red[qd][2 * lane] = p0;
-        red[qd][2 * lane + 1] = p1;
-        __syncthreads();
+    CHAIN8_STAMP(4);
+    if (has1) {
+        if (wave != 0) {
+            double p0 = 0.0, p1 = 0.0;
+            if (has2) CHAIN8_TAIL(B, q2, X + (long)(k + 2) * 128);
+            CHAIN8_TAIL(A, q1, X + (long)(k + 1) * 128);
+            CHAIN8_STAMP(5);
+            red[wave][2 * lane] = p0;
+            red[wave][2 * lane + 1] = p1;
+        }
+        chain_lds_barrier();
         if (tid < 128) {
             double s = 0.0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) s += red[q][tid];
+            for (int q = 1; q <= CH_SW; q++) s += red[q][tid];
             u -= s;
         }
     }
     if (tid < 128) chain_publish(X + (long)k * 128 + tid, u);
-    if (tch0 + tch1 == 0x7fffff17) vv[0] = 1.0;                  // keeps the touches alive
+#undef CHAIN8_STAMP
+#undef CHAIN8_STAMP_T
+    if (tch == 0x7fffff17) vv[0] = 1.0;                          // keeps the touches alive
     if (trace && tid == 0) trace[pos] = wall_clock64();          // JAICOV_CHAIN_TRACE: when each link was published (100 MHz)
-#undef CHAIN8_USE
 }
 
-__global__ __launch_bounds__(CHAIN8_THREADS) void forwardsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
-                                                                             const double *__restrict__ Ft, const double *__restrict__ Bv, double *Z,
-                                                                             int nb, int remap, long long *trace) {
-    __shared__ double red[128][65];                // per-lane partial sums of the 128 rows; the tail's partial sums ([8][128]) afterwards
-    __shared__ double part[4][128];
-    __shared__ double comb[4][128];
-    __shared__ double vv[128];
-    __shared__ double Wl[128 * 129 / 2];           // inv(L_kk), lower triangle packed by columns: (row, c) at c * 128 - c (c - 1) / 2 + (row - c)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int qd = __builtin_amdgcn_readfirstlane(tid >> 6);   // stream: rows 16*qd .. 16*qd+15, columns 2*lane, 2*lane+1
-    bool local;
-    const int k = chain_position(nb, remap, local);
-    if (k >= nb) return;
-    const bool has_prev = k > 0;
-    const int n = has_prev ? k - 1 : 0;            // streamed blocks: block i is L[k][i]
-    const int di = tid & 127, h4 = tid >> 7;       // diagonal phase: output row di, columns 32*h4 .. 32*h4+31
-    {
-        const double *w = invd + (long)k * 16384 + (long)di * 128 + 32 * h4;     // row di of inv(L_kk)
-        d4_t t[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) t[c] = *reinterpret_cast<const d4_t *>(w + 4 * c);
-#pragma unroll
-        for (int c = 0; c < 32; c++) {
-            const int cc = 32 * h4 + c;
-            if (cc <= di) Wl[cc * 128 - cc * (cc - 1) / 2 + (di - cc)] = t[c >> 2][c & 3];
-        }
-    }
-    double bk = 0.0;
-    if (tid < 128) bk = Bv[k * 128 + tid];
-    __syncthreads();
-    const char *fk = reinterpret_cast<const char *>(Ft + (long)k * 16384 + (long)(16 * qd) * 128);
-    const char *lrow = reinterpret_cast<const char *>(L + (long)(k * 128 + 16 * qd) * ld);
-    const unsigned voff = 16u * (unsigned)lane;
-    const double *zq = Z + 2 * lane;               // + 128 * block: the two values of this lane's columns
-    d2_t A[16], B[16];
-    double acc[16];
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[r] = 0.0;
-#define CHAIN8_USE(buf, z0, z1, keep)                                                                    \
-    {                                                                                                    \
-        const double f0 = (keep) ? z0 : 0.0, f1 = (keep) ? z1 : 0.0;                                     \
-        _Pragma("unroll") for (int r = 0; r < 16; r++) acc[r] = __builtin_fma(buf[r].y, f1, __builtin_fma(buf[r].x, f0, acc[r])); \
-    }
-    const char *dummy = reinterpret_cast<const char *>(invd);
-    unsigned long long pa0 = chain_poll_issue(zq), pa1 = chain_poll_issue(zq + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    CHAIN8_LOAD(A, 0 < n, lrow, dummy);
-    CHAIN8_LOAD(B, 1 < n, lrow + 1024, dummy);
-    const int tch0 = *reinterpret_cast<const int *>(Ft + (long)k * 16384 + 32 * tid), tch1 = *reinterpret_cast<const int *>(Ft + (long)k * 16384 + 32 * tid + 16);
-    for (int i = 0; i < n; i += 2) {
-        const int jb = i + 1 < n ? i + 1 : i;                       // no such block: an already published result, product discarded
-        const int jn = i + 2 < n ? i + 2 : i;
-        const double za0 = chain_poll_finish(pa0, zq + (long)i * 128), za1 = chain_poll_finish(pa1, zq + (long)i * 128 + 1);
-        CHAIN8_USE(A, za0, za1, true);
-        const unsigned long long pb0 = chain_poll_issue(zq + (long)jb * 128), pb1 = chain_poll_issue(zq + (long)jb * 128 + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        CHAIN8_LOAD(A, i + 2 < n, lrow + (long)(i + 2) * 1024, dummy);
-        const double zb0 = chain_poll_finish(pb0, zq + (long)jb * 128), zb1 = chain_poll_finish(pb1, zq + (long)jb * 128 + 1);
-        CHAIN8_USE(B, zb0, zb1, i + 1 < n);
-        pa0 = chain_poll_issue(zq + (long)jn * 128);
-        pa1 = chain_poll_issue(zq + (long)jn * 128 + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        CHAIN8_LOAD(B, i + 3 < n, lrow + (long)(i + 3) * 1024, dummy);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; r++) A[r] = *reinterpret_cast<const d2_t *>(fk + (long)r * 1024 + voff);      // Ft_k
-#pragma unroll
-    for (int r = 0; r < 16; r++) red[16 * qd + r][lane] = acc[r];
-    __syncthreads();
-    {
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < 16; c++) s += red[di][16 * h4 + c];
-        part[h4][di] = s;
-    }
-    __syncthreads();
-    if (tid < 128) vv[tid] = bk - ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]));
-    __syncthreads();
-    {   // u = W_k (b_k - S)
-        double out = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < 32; c++) {
-            const int cc = 32 * h4 + c;
-            out += (cc <= di ? Wl[cc * 128 - cc * (cc - 1) / 2 + (di - cc)] : 0.0) * vv[cc];
-        }
-        comb[h4][di] = out;
-    }
-    __syncthreads();
-    double u = 0.0;
-    if (tid < 128) u = (comb[0][tid] + comb[1][tid]) + (comb[2][tid] + comb[3][tid]);
-    if (has_prev) {
-        double *red2 = &red[0][0];                 // [8][128]; every read of red[][] is two barriers back
-        const double zv = chain_wait_tail(Z + (long)(k - 1) * 128 + 16 * qd + (lane & 15), local);
-        double p0 = 0.0, p1 = 0.0;
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const double zr = readlane_f64(zv, r); p0 += A[r].x * zr; p1 += A[r].y * zr; }
-        red2[qd * 128 + 2 * lane] = p0;
-        red2[qd * 128 + 2 * lane + 1] = p1;
-        __syncthreads();
-        if (tid < 128) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) s += red2[q * 128 + tid];
-            u -= s;
-        }
-    }
-    if (tid < 128) chain_publish(Z + (long)k * 128 + tid, u);
-    if (tch0 + tch1 == 0x7fffff17) vv[0] = 1.0;                  // keeps the touches alive
-    if (trace && tid == 0) trace[k] = wall_clock64();
-#undef CHAIN8_USE
-}
+#undef CHAIN8_LOAD_PM
+#undef CHAIN8_TAIL
+#undef CHAIN8_TAIL_SRC
 #undef CHAIN8_LOAD
 
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
@@ -964,31 +940,20 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
     return hipGetLastError();
 }
 
-// chain positions dealt to the XCDs in runs (chain_position()): only when the whole grid is resident at once
-static int chain_remap(int nb) {
-    static const bool off = getenv("JAICOV_CHAIN_NO_REMAP") != nullptr;
-    return (!off && nb >= 16 && nb <= 256) ? 1 : 0;
-}
-
-// P_k = L[k+1][k] W_k (k < nb-1) and Ft_k = (W_k L[k][k-1])' (k > 0) of the factor at hand, once per factorisation
-// (backsolve_chain8_kernel / forwardsolve_chain8_kernel).  pm = [P_0 .. P_{nb-1}][Ft_0 .. Ft_{nb-1}], 128 x 128 row-major each.
+// The two blocks below every diagonal block multiplied into its inverse, once per factorisation, for backsolve_chain8_kernel:
+// P1_k = L[k+1][k] W_k,  P2_k = L[k+2][k] W_k.  pm = [P1_0 .. P1_{nb-1}][P2_0 ..], 128 x 128 row-major each (blocks that do not
+// exist stay zero).
 hipError_t DenseSolver::premultiply() {
     if (pm_ready || !pm) return hipSuccess;
     const int nb = nfact / 128;
-    if (nb > 1) {
-        const long bstride = 128 * (ld + 1);
+    const long bstride = 128 * (ld + 1);
+    for (int m = 1; m <= 2 && m < nb; m++) {
         GemmArgs p{};
-        p.A = L + 128 * ld; p.lda = ld; p.strideA = bstride;                   // L[k+1][k]   (KC)
+        p.A = L + (long)m * 128 * ld; p.lda = ld; p.strideA = bstride;         // L[k+m][k]   (KC)
         p.B = invd; p.ldb = 128; p.strideB = 16384;                           // W_k (k, j) row-major (XC)
-        p.C = pm; p.ldc = 128; p.strideC = 16384;
+        p.C = pm + (size_t)(m - 1) * nb * 16384; p.ldc = 128; p.strideC = 16384;
         p.M = p.N = p.K = 128; p.alpha = 1.0; p.beta = 0.0; p.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, p, nb - 1, 0));
-        GemmArgs f{};                                                          // Ft_k = L[k][k-1]' W_k', k >= 1
-        f.A = L + 128 * ld; f.lda = ld; f.strideA = bstride;                   // L[k][k-1] read transposed (XC)
-        f.B = invd + 16384; f.ldb = 128; f.strideB = 16384;                   // W_k' (k, j) = W_k[j][k] (KC)
-        f.C = pm + (size_t)(nb + 1) * 16384; f.ldc = 128; f.strideC = 16384;
-        f.M = f.N = f.K = 128; f.alpha = 1.0; f.beta = 0.0; f.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(stream, LAY_XC, LAY_KC, f, nb - 1, 0));
+        HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, p, nb - m, 0));
     }
     pm_ready = true;
     return hipGetLastError();
@@ -1002,8 +967,8 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;      // the chains without pre-multiplied last blocks
     if (nrhs <= 1 && pm && !plain) {
         HIPCHK(premultiply());
-        const int remap = chain_remap(nb);
-        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(remap ? 8 * ((nb + 7) / 8) : nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, rhs_row(0), X, nb, remap, ab, (long long *)nullptr);
+        const size_t blk = (size_t)nb * 16384;
+        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, pm + blk, rhs_row(0), X, nb, ab, (long long *)nullptr);
     } else if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
@@ -1020,22 +985,24 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
     static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;
     if (pm && !plain) {
         HIPCHK(premultiply());
-        const int remap = chain_remap(nb);
-        const dim3 grid(remap ? 8 * ((nb + 7) / 8) : nb);
-        static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the two chains on stderr
+        static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the backward chain on stderr
         long long *tr = nullptr;
-        if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)2 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)2 * nb * sizeof(long long), stream)); }
-        hipLaunchKernelGGL(forwardsolve_chain8_kernel, grid, dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm + (size_t)nb * 16384, b, tmp, nb, remap, tr);
-        hipLaunchKernelGGL(backsolve_chain8_kernel, grid, dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, tmp, X, nb, remap, (const int *)nullptr, tr ? tr + nb : nullptr);
+        if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)9 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)9 * nb * sizeof(long long), stream)); }
+        const size_t blk = (size_t)nb * 16384;
+        hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
+        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, pm + blk, tmp, X, nb, (const int *)nullptr, tr);
         if (tracing) {
-            std::vector<long long> h((size_t)2 * nb);
+            std::vector<long long> h((size_t)9 * nb);
             HIPCHK(hipMemcpyAsync(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             hipFree(tr);
-            for (int c = 0; c < 2; c++) {
-                fprintf(stderr, "[jaicov chain trace] %s, nb %d, link times in 10 ns:", c ? "backward" : "forward", nb);
-                for (int q = 1; q < nb; q++) fprintf(stderr, " %lld", h[(size_t)c * nb + q] - h[(size_t)c * nb + q - 1]);
-                fprintf(stderr, "\n");
+            fprintf(stderr, "[jaicov chain trace] backward, nb %d, link times in 10 ns:", nb);
+            for (int q = 1; q < nb; q++) fprintf(stderr, " %lld", h[q] - h[q - 1]);
+            fprintf(stderr, "\n[jaicov chain trace] per position: start, stream done (wave 1), barrier 1, barrier 2, u ready, tails done, polling wave done, stream done (wave 7), relative to the predecessor's publication (10 ns)\n");
+            for (int q = 1; q < nb; q += (q < 12 ? 1 : 9)) {
+                fprintf(stderr, "   pos %3d:", q);
+                for (int c = 0; c < 8; c++) fprintf(stderr, " %6lld", h[(size_t)nb + 8 * q + c] - h[q - 1]);
+                fprintf(stderr, "   published %6lld\n", h[q] - h[q - 1]);
             }
         }
         return hipGetLastError();
