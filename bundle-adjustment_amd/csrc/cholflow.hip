@@ -128,6 +128,10 @@ __device__ __forceinline__ void store_wt2(double *p, d2_t v) {
     asm volatile("s_nop 15\n\ts_nop 7\n\tglobal_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// pause between two polls of a wait that has lasted more than 32 polls, in units of 64 clocks (s_sleep)
+#ifndef FLOW_LONG_NAP
+#define FLOW_LONG_NAP 40
+#endif
 
 #define FLOW_OPAQUE_TID(name) int name = tid; asm volatile("" : "+v"(name))
 
@@ -150,7 +154,7 @@ __device__ __forceinline__ bool flow_spin(const int *flag, int want, int *ctrl, 
         if (flow_ld(flag) >= want) break;
         if (++spins < 32) __builtin_amdgcn_s_sleep(4);
         else {
-            __builtin_amdgcn_s_sleep(40);
+            __builtin_amdgcn_s_sleep(FLOW_LONG_NAP);
             if ((spins & 31) == 0) {
                 if (flow_ld_sys(flag) >= want || flow_ld_rmw(flag) >= want) {      // set; did the plain poll only just miss it, or does it still not see it?
                     atomicAdd(ctrl + FLOW_STALE, 1);
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                             if (cnt > 0) break;
                             if (++spins < 32) __builtin_amdgcn_s_sleep(4);
                             else {
-                                __builtin_amdgcn_s_sleep(40);
+                                __builtin_amdgcn_s_sleep(FLOW_LONG_NAP);
                                 if ((spins & 31) == 0) {
                                     if (wall_clock64() - t0 > 100000) {       // > 1 ms: whatever this CU / XCD still holds of the flag lines goes
                                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
