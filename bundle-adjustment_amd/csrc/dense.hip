@@ -520,14 +520,19 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     }
     chain_lds_barrier();
     CHAIN8_STAMP(3);
-    {
-        double out = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < 32; r++) {
+    {   // branch-free: entries above the diagonal read the row's first entry and are dropped
+        double o0 = 0.0, o1 = 0.0;
+        int base = 16 * h4 * (32 * h4 + 1);                       // rr (rr + 1) / 2 at rr = 32 h4
+#pragma unroll
+        for (int r = 0; r < 32; r += 2) {
             const int rr = 32 * h4 + r;
-            out += (di <= rr ? Wl[rr * (rr + 1) / 2 + di] : 0.0) * vv[rr];
+            const double w0 = Wl[base + (di <= rr ? di : 0)];
+            const double w1 = Wl[base + rr + 1 + (di <= rr + 1 ? di : 0)];
+            o0 += (di <= rr ? w0 : 0.0) * vv[rr];
+            o1 += (di <= rr + 1 ? w1 : 0.0) * vv[rr + 1];
+            base += 2 * rr + 3;
         }
-        comb[h4][di] = out;
+        comb[h4][di] = o0 + o1;
     }
     chain_lds_barrier();
     double u = 0.0;
