@@ -523,7 +523,7 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     {   // branch-free: entries above the diagonal read the row's first entry and are dropped
         double o0 = 0.0, o1 = 0.0;
         int base = 16 * h4 * (32 * h4 + 1);                       // rr (rr + 1) / 2 at rr = 32 h4
-#pragma unroll
+#pragma unroll 4
         for (int r = 0; r < 32; r += 2) {
             const int rr = 32 * h4 + r;
             const double w0 = Wl[base + (di <= rr ? di : 0)];
