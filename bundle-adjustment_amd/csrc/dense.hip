@@ -381,13 +381,21 @@ __device__ __forceinline__ void chain_ring_done(ChainRing &rg, int slot, int lan
 // block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Row r of a wave's share is row
 // min(r, nrows - 1) (waves with 18 rows read their last row twice, its product is dropped).  Loads past the end of the stream are
 // issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1.
+// block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Loads past the end of the stream are
+// issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1.
+// A __builtin_amdgcn_sched_barrier(0) stands on either side of a refill: without it the scheduler moves the refill loads about,
+// and the register copies the compiler places on the loop's back edge (it renames one buffer: 38 v_mov_b64) came behind an
+// s_waitcnt vmcnt(0) -- the refill just issued had to land before the loop went on, and the second buffer bought nothing.  With
+// it the copies wait for the older refill only (vmcnt(19)), which the next use needs anyway.
 #define CHAIN8_LOAD(buf, real, ptr_real, ptr_dummy)                                                                       \
     {                                                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
         const char *bp = (real) ? (ptr_real) : (ptr_dummy);                                                                \
         const long st = (real) ? ld * 8 : 0;                                                                               \
         const unsigned vo = (real) ? voff : 0u;                                                                            \
         _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
             buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * st + vo);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }
 
 // the pre-multiplied block `src` (128 x 128, row-major) of a streaming wave: rows r0.., columns 2*lane, 2*lane+1
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     const unsigned voff = 16u * (unsigned)lane;
     const char *dummy = reinterpret_cast<const char *>(invd);
     d2_t A[CH_ROWS], B[CH_ROWS];                   // two stream buffers; P1_k and P2_k behind the stream
+
     double acc0 = 0.0, acc1 = 0.0;
     unsigned long long q1 = BS_UNSET, q2 = BS_UNSET;
     // P1_k, P2_k are fetched behind the stream (their registers are the stream's until then); one dword per line now, so that they
