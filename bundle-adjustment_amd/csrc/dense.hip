@@ -292,10 +292,11 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 //    partial sums.  The barriers behind the stream order LDS traffic only (chain_lds_barrier()).
 // Same flag protocol towards the other workgroups (results preset to the all-ones pattern, relaxed agent-scope atomics), same
 // progress argument (a workgroup waits only for workgroups with a smaller index) and the same bounded spin as above.
-// What it gives at config 4 (118 links): 0.41 -> 0.345 ms.  The links now cost ~2.9 us on average: the path from "x_{k+3} published"
-// to "x_k published" inside one workgroup is still ~9 us (trace: the streaming waves finish the stream up to 3.5 us apart, 1.9 us
-// for the product with inv(L_kk)), three links' worth.  The forward chain keeps its first form: this layout needs 19 row sums per
-// lane there and spills.
+// What it gives at config 4 (118 links): 0.41 -> 0.34 ms.  The links now cost ~2.9 us on average: the path from "x_{k+3} published"
+// to "x_k published" inside one workgroup is still ~9 us, three links' worth (trace, relative to the predecessor's publication:
+// polling wave has x_{k+3} at -4.7 us, streaming waves done -3.5 .. -1.5, first barrier -0.5, u ready +1.4, both products done
+// +2.2, published +3.2) -- every phase of a few LDS round trips and a barrier among eight waves costs ~1 us.  The forward chain
+// keeps its first form: this layout needs 19 row sums per lane there and spills.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -406,8 +407,8 @@ __device__ __forceinline__ void chain_ring_done(ChainRing &rg, int slot, int lan
             buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * 1024 + voff);                    \
     }
 // p0, p1 += buf' v for the rows of this wave, v = the 128 values at src (published by a predecessor); lanes 0..18 poll.  The first
-// poll (q) went out in front of the u-phase (CHAIN8_TAIL_ISSUE): a memory round trip is ~1.5 us, three of them one after the other
-// on the path x_{k+3} -> x_k were most of what that path cost
+// poll (q) went out in front of the u-phase (chain_tail_issue): a poll is a memory round trip, and three of them one after the
+// other lie on the path x_{k+3} -> x_k
 #define CHAIN8_TAIL_SRC(src) ((src) + r0 + ((lane < CH_ROWS ? lane : CH_ROWS - 1) < nrows ? (lane < CH_ROWS ? lane : CH_ROWS - 1) : last_row))
 #define CHAIN8_TAIL(buf, q, src)                                                                                           \
     {                                                                                                                      \
