@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 // The backward chain for ONE right-hand side: a polling wave and seven streaming waves per workgroup (round 3).
 //
 // A link of the chain above takes 3.4 us although the hop itself -- agent-scope store in one workgroup, agent-scope load in
-// another -- takes 0.53 us inside an XCD and 0.59 us across XCDs (scripts/micro/hop_latency.hip; the same test shows that a
+// another -- takes 0.42-0.53 us inside an XCD and 0.59-0.65 us across XCDs (scripts/micro/hop_latency.hip; the same test shows that a
 // workgroup-scope load (sc0) is served by the CU's L1 and NEVER sees another workgroup's store, so there is no cheaper poll for
 // neighbours on one XCD).  The rest is how a workgroup waits and what it still has to do once the last result it depends on is
 // there (JAICOV_CHAIN_TRACE prints the link times and the phases of a workgroup):
