@@ -55,6 +55,19 @@ def test_dense_spd_solve_and_inverse(n):
     np.testing.assert_allclose(packed_to_full(ap, n), np.linalg.inv(S), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [100, 200, 384, 500, 640, 1100, 2100, 4200])
+def test_dense_spd_solve_one_right_hand_side(n):
+    """ONE right-hand side takes the polling-wave form of the backward chain (backsolve_chain8_kernel, dense.hip): 1, 2, 3, 4, 5, 9, 17
+    and 33 block columns -- no predecessor, one and two pre-multiplied blocks only, streams of odd and even length, and streams
+    longer than the ring between the polling wave and the streaming waves (8 slots)."""
+    rng = np.random.default_rng(7 * n)
+    G = rng.normal(size=(n, n + 20))
+    S = G @ G.T / n + np.eye(n)
+    b = rng.normal(size=(1, n))
+    x, _, _ = engine.dense_spd_solve_packed(full_to_packed(S), b)
+    np.testing.assert_allclose(x, np.linalg.solve(S, b.T).T, rtol=1e-10, atol=1e-12)
+
+
 @pytest.mark.parametrize("n", [128, 300, 1000, 2100])
 def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
     """The dataflow Cholesky (csrc/cholflow.hip) is the default from 24 block columns on; forced here on 1, 3, 8 and 17
