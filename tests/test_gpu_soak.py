@@ -3,7 +3,8 @@
 The dataflow Cholesky's waits are bounded; a wait that runs out makes `solve` repeat the factorisation (engine.hip) and counts in
 jaicov_neq_kernel_stats()[6].  Round 2 saw one such stall per 300-3 600 factorisations until the last workgroups on the chain
 workgroups' XCDs were taken out (cholflow.hip, "keep"); 16 000 clean factorisations since.  150 passes here by default (5 s);
-JAICOV_SOAK_PASSES=4000 for a real soak (2 min)."""
+JAICOV_SOAK_PASSES=4000 for a real soak (2 min).  Every pass also runs the substitution chains (dense.hip: a lost link
+would show as NaNs in the step): 14 000 passes = 28 000 launches of the polling-wave backward chain at the end of round 3, clean."""
 import os
 
 import numpy as np
@@ -25,6 +26,8 @@ def test_no_factorisation_is_abandoned_over_many_passes(cfg4_scene):
         eng.build(s2, 0.0)
         dx = eng.solve(False)
         assert np.isfinite(dx).all(), i      # a lost link of a substitution chain shows up as NaNs (dense.hip)
+        if i % 1000 == 999:
+            print(f"soak: {i + 1} passes", flush=True)     # (a long run must not look hung to the GPU pool's watchdog)
         if ref is None:
             ref = dx
         elif i % 25 == 0:       # same system every pass (no update): the step may differ by the assembly's rounding only
