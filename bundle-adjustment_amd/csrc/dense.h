@@ -38,7 +38,7 @@ struct DenseSolver {
     const int2 *trtri_tile_order(int tm, int tn, int kind);
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
-    double *pm = nullptr;      // 4 x (n/128) x 128 x 128 : the chains' pre-multiplied blocks P1, Ft1, P2, Ft2 (premultiply())
+    double *pm = nullptr;      // 5 x (n/128) x 128 x 128 : the backward chain's pre-multiplied blocks P_1 .. P_5 (premultiply(), dense.hip CH_PM)
     bool pm_ready = false;     // pm belongs to the factor at hand (potrf() clears it)
     hipError_t premultiply();
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse

@@ -283,20 +283,22 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 //    in flight -- and for a block with the exact s_waitcnt vmcnt the compiler derives from straight-line code (all loads are
 //    unconditional; past the end of the stream they re-read one 16-byte piece that sits in the L1).  No workgroup barrier in
 //    the loop;
-//  * the LAST TWO blocks of every stream are multiplied into the diagonal inverse beforehand,
-//        x_k = W_k'(z_k - S) - P1_k' x_{k+1} - P2_k' x_{k+2},   P1_k = L[k+1][k] W_k,  P2_k = L[k+2][k] W_k
-//    (DenseSolver::premultiply(): two batched 128^3 MFMA GEMMs after the factorisation), so that u = W_k'(z_k - S) -- the
-//    reduction, three barriers, the product with inv(L_kk) from LDS -- is formed two links early.  When x_{k+2} and x_{k+1}
-//    appear, every streaming wave polls the values that multiply its rows itself (nothing else is in flight by then; the first
-//    polls go out in front of the u-phase), broadcasts them with v_readlane, and ONE exchange through LDS + barrier joins the
-//    partial sums.  The barriers behind the stream order LDS traffic only (chain_lds_barrier()).
+//  * the LAST blocks of every stream (CH_PM = 5, or 4 where that makes the rest an even number) are multiplied into the diagonal
+//    inverse beforehand,
+//        x_k = W_k'(z_k - S) - sum_m P_m[k]' x_{k+m},   P_m[k] = L[k+m][k] W_k,   S = the sum over the other blocks
+//    (DenseSolver::premultiply(): one batched launch of 128^3 MFMA GEMMs after the factorisation), so that u = W_k'(z_k - S) --
+//    the reduction over the waves, three barriers, the product with inv(L_kk) from LDS: ~2.5 us -- is formed four or five links
+//    before the workgroup's turn.  The pre-multiplied blocks are streamed like the others (same buffers, same ring); what is
+//    left of a link is: the polling wave sees x_{k+1}, hands it over, 38 FMAs per streaming thread, ONE exchange through LDS +
+//    barrier, store.  The barriers behind the stream order LDS traffic only (chain_lds_barrier()).
 // Same flag protocol towards the other workgroups (results preset to the all-ones pattern, relaxed agent-scope atomics), same
 // progress argument (a workgroup waits only for workgroups with a smaller index) and the same bounded spin as above.
-// What it gives at config 4 (118 links): 0.41 -> 0.34 ms.  The links now cost ~2.9 us on average: the path from "x_{k+3} published"
-// to "x_k published" inside one workgroup is still ~9 us, three links' worth (trace, relative to the predecessor's publication:
-// polling wave has x_{k+3} at -4.7 us, streaming waves done -3.5 .. -1.5, first barrier -0.5, u ready +1.4, both products done
-// +2.2, published +3.2) -- every phase of a few LDS round trips and a barrier among eight waves costs ~1 us.  The forward chain
-// keeps its first form: this layout needs 19 row sums per lane there and spills.
+// What it gives at config 4 (118 links): 0.41 -> 0.31 ms, links of 2.6 us on average (1.5 - 2.1 and 2.7 - 3.9 in turn; the first
+// links of a chain, whose successors are waiting, take 1.2 - 1.5).  Steps on the way, all measured: polling wave + ring + two
+// pre-multiplied blocks resident behind the stream 0.345 ms (the u-phase still ended after the predecessor had published);
+// every wave polling the last two results itself instead of the polling wave: no gain; touching the pre-multiplied blocks into the
+// L2 ahead of their loads: 0.41 ms (the polls queue behind the touches).  The forward chain keeps its first form: this layout
+// needs 19 row sums per lane there and spills.
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
@@ -307,19 +309,6 @@ __device__ __forceinline__ unsigned long long chain_poll(const unsigned long lon
     return (spin & 1023) == 1023 ? __hip_atomic_fetch_or(const_cast<unsigned long long *>(p), 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                  : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// the waits on the chain's critical path: first poll (issued early), then repeated until the value is there
-__device__ __forceinline__ unsigned long long chain_tail_issue(const double *src) {
-    return __hip_atomic_load(reinterpret_cast<const unsigned long long *>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double chain_tail_finish(unsigned long long b, const double *src) {
-    const unsigned long long *p = reinterpret_cast<const unsigned long long *>(src);
-    int spin = 0;
-    while (b == BS_UNSET && ++spin < BS_SPIN_MAX) {
-        __builtin_amdgcn_s_sleep(1);
-        b = chain_poll(p, spin);
-    }
-    return __longlong_as_double((long long)b);
-}
 __device__ __forceinline__ void chain_publish(double *dst, double v) {
     unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     if (bits == BS_UNSET) bits = 0x7FF8000000000000ull;
@@ -329,6 +318,7 @@ constexpr int CHAIN8_THREADS = 512;
 constexpr int CH_RD = 8;              // slots of the ring between the polling wave and the streaming waves
 constexpr int CH_SW = 7;              // streaming waves
 constexpr int CH_ROWS = 19;           // rows of a block per streaming wave: waves 1..5 take 18, waves 6 and 7 take 19
+constexpr int CH_PM = 5;              // blocks below a diagonal block that are multiplied into its inverse (DenseSolver::premultiply)
 struct ChainRing {
     double xs[CH_RD + 1][128];        // published results, in the order of the stream; slot CH_RD: zeros (a step without a block)
     int ready[CH_RD];                 // 1 + index of the stream entry the slot holds
@@ -342,13 +332,6 @@ __device__ __forceinline__ void chain_ring_init(ChainRing &rg, int tid) {
 // vmcnt(0)): behind the stream those are the two pre-multiplied blocks and the first polls for the predecessors' results, which
 // the u-phase does not need -- its three barriers cost 7 us that way (JAICOV_CHAIN_TRACE), on the chain's critical path.
 __device__ __forceinline__ void chain_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// one dword of every 128-byte line of two 128 x 128 blocks, by one wave (pulls them into this XCD's L2)
-__device__ __forceinline__ int chain_touch2(const double *a, const double *b, int lane) {
-    int t = 0;
-#pragma unroll
-    for (int q = 0; q < 16; q++) t += *reinterpret_cast<const int *>(a + 16 * (64 * q + lane)) + *reinterpret_cast<const int *>(b + 16 * (64 * q + lane));
-    return t;
-}
 // the polling wave: entry i of the stream = the 128 values at src
 __device__ __forceinline__ void chain_ring_put(ChainRing &rg, int i, const double *src, int lane) {
     const int slot = i & (CH_RD - 1);
@@ -379,52 +362,9 @@ __device__ __forceinline__ void chain_ring_done(ChainRing &rg, int slot, int lan
     if (lane == 0) __hip_atomic_fetch_add(&rg.consumed[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Row r of a wave's share is row
-// min(r, nrows - 1) (waves with 18 rows read their last row twice, its product is dropped).  Loads past the end of the stream are
-// issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1.
-// block addresses = wave-uniform row base (scalar registers) + a 32-bit lane offset.  Loads past the end of the stream are
-// issued all the same (straight-line code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1.
-// A __builtin_amdgcn_sched_barrier(0) stands on either side of a refill: without it the scheduler moves the refill loads about,
-// and the register copies the compiler places on the loop's back edge (it renames one buffer: 38 v_mov_b64) came behind an
-// s_waitcnt vmcnt(0) -- the refill just issued had to land before the loop went on, and the second buffer bought nothing.  With
-// it the copies wait for the older refill only (vmcnt(19)), which the next use needs anyway.
-#define CHAIN8_LOAD(buf, real, ptr_real, ptr_dummy)                                                                       \
-    {                                                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        const char *bp = (real) ? (ptr_real) : (ptr_dummy);                                                                \
-        const long st = (real) ? ld * 8 : 0;                                                                               \
-        const unsigned vo = (real) ? voff : 0u;                                                                            \
-        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
-            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * st + vo);                        \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-    }
-
-// the pre-multiplied block `src` (128 x 128, row-major) of a streaming wave: rows r0.., columns 2*lane, 2*lane+1
-#define CHAIN8_LOAD_PM(buf, src)                                                                                           \
-    {                                                                                                                      \
-        const char *bp = reinterpret_cast<const char *>((src) + (long)r0 * 128);                                           \
-        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
-            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * 1024 + voff);                    \
-    }
-// p0, p1 += buf' v for the rows of this wave, v = the 128 values at src (published by a predecessor); lanes 0..18 poll.  The first
-// poll (q) went out in front of the u-phase (chain_tail_issue): a poll is a memory round trip, and three of them one after the
-// other lie on the path x_{k+3} -> x_k
-#define CHAIN8_TAIL_SRC(src) ((src) + r0 + ((lane < CH_ROWS ? lane : CH_ROWS - 1) < nrows ? (lane < CH_ROWS ? lane : CH_ROWS - 1) : last_row))
-#define CHAIN8_TAIL(buf, q, src)                                                                                           \
-    {                                                                                                                      \
-        const double xw = chain_tail_finish(q, CHAIN8_TAIL_SRC(src));                                                      \
-        const double xv = (lane == 18 && nrows == 18) ? 0.0 : xw;                                                          \
-        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++) {                                                              \
-            const double xr = readlane_f64(xv, r);                                                                         \
-            p0 += buf[r].x * xr;                                                                                           \
-            p1 += buf[r].y * xr;                                                                                           \
-        }                                                                                                                  \
-    }
-
 __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
-                                                                          const double *__restrict__ P1, const double *__restrict__ P2,
-                                                                          const double *__restrict__ Z, double *X, int nb,
-                                                                          const int *abort_word, long long *trace) {
+                                                                          const double *__restrict__ PM, const double *__restrict__ Z,
+                                                                          double *X, int nb, const int *abort_word, long long *trace) {
     __shared__ double red[8][128];
     __shared__ double comb[4][128];
     __shared__ double vv[128];
@@ -435,8 +375,13 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pos = blockIdx.x;                    // position in the chain
     const int k = nb - 1 - pos;
-    const bool has1 = k + 1 < nb, has2 = k + 2 < nb;           // x_{k+1} through P1_k, x_{k+2} through P2_k
-    const int n = has2 ? nb - 3 - k : 0;           // streamed blocks: entry i is L[nb-1-i][k] with x_{nb-1-i}
+    // The c = pos predecessors x_{k+1} .. x_{nb-1} are ONE stream, in the order they are published (x_{nb-1} first):
+    //   entries 0 .. n_plain-1   blocks L[nb-1-i][k] of the factor, summed into S;  u = W_k'(z_k - S) is formed behind them,
+    //   entries n_plain .. c-1   the pre-multiplied blocks P_m, m = c - i = npre .. 1, whose products go straight into x_k.
+    // npre = CH_PM or CH_PM - 1, whichever makes n_plain even (the first loop then has no half step), or all of them.
+    const int c = pos;
+    const int npre = c <= CH_PM ? c : (((c - CH_PM) & 1) ? CH_PM - 1 : CH_PM);
+    const int n_plain = c - npre;
     const int di = tid & 127, h4 = tid >> 7;       // diagonal phase: output di, operand quarter h4
     // streaming waves 1..7: rows r0 .. r0 + nrows - 1, columns 2*lane, 2*lane+1
     const int nrows = wave <= 5 ? 18 : 19;
@@ -448,13 +393,13 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     chain_ring_init(ring, tid);
     {   // inv(L_kk) -> LDS
         const double *w = invd + (long)k * 16384 + (long)(32 * h4) * 128 + di;
-        double t[32];
+        double tw[32];
 #pragma unroll
-        for (int r = 0; r < 32; r++) t[r] = w[(long)r * 128];
+        for (int r = 0; r < 32; r++) tw[r] = w[(long)r * 128];
 #pragma unroll
         for (int r = 0; r < 32; r++) {
             const int rr = 32 * h4 + r;
-            if (di <= rr) Wl[rr * (rr + 1) / 2 + di] = t[r];
+            if (di <= rr) Wl[rr * (rr + 1) / 2 + di] = tw[r];
         }
     }
     double zk = 0.0;
@@ -464,26 +409,28 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     const long bstep = 128 * ld * 8;               // bytes from one block row to the next
     const unsigned voff = 16u * (unsigned)lane;
     const char *dummy = reinterpret_cast<const char *>(invd);
-    d2_t A[CH_ROWS], B[CH_ROWS];                   // two stream buffers; P1_k and P2_k behind the stream
-
-    double acc0 = 0.0, acc1 = 0.0;
-    unsigned long long q1 = BS_UNSET, q2 = BS_UNSET;
-    // P1_k, P2_k are fetched behind the stream (their registers are the stream's until then); one dword per line now, so that they
-    // come from the L2 then
-    const double *p1k = P1 + (long)k * 16384, *p2k = P2 + (long)k * 16384;
-    const int tch = *reinterpret_cast<const int *>(p1k + 32 * tid) + *reinterpret_cast<const int *>(p1k + 32 * tid + 16) +
-                    *reinterpret_cast<const int *>(p2k + 32 * tid) + *reinterpret_cast<const int *>(p2k + 32 * tid + 16);
-    if (wave == 0) {
-        int tsum = 0;
-        for (int i = 0; i < n; i++) {
-            if (i == n - 5) tsum = chain_touch2(p1k, p2k, lane);      // P1_k, P2_k back into the L2 shortly before they are fetched
-            chain_ring_put(ring, i, X + (long)(nb - 1 - i) * 128, lane);
-        }
-        if (tsum == 0x7fffff17) vv[1] = 1.0;
-        CHAIN8_STAMP_T(6, 0);
-    } else {
-        const int xlane = r0 + (lane < 18 ? lane : last_row);
-        const bool xdrop = lane == 18 && nrows == 18;
+    const double *pmk = PM + (long)k * 16384;      // P_m of this column: pmk + (m - 1) * nb * 16384
+    const long pmstep = (long)nb * 16384;
+    d2_t A[CH_ROWS], B[CH_ROWS];                   // two stream buffers; P_1 and P_2 behind the stream
+    double acc0 = 0.0, acc1 = 0.0;                 // S (streamed blocks of the factor), then the pre-multiplied part
+    // Stream entry i into a buffer: a block of the factor, a pre-multiplied block, or (past the end) nothing.  Addresses =
+    // wave-uniform row base (scalar registers) + a 32-bit lane offset.  Loads past the end are issued all the same (straight-line
+    // code keeps the s_waitcnt counts exact) but read one 16-byte piece that is in the L1.  A __builtin_amdgcn_sched_barrier(0)
+    // stands on either side: without it the scheduler moves the refill loads about, and the register copies the compiler places on
+    // the loop's back edge (it renames one buffer: 38 v_mov_b64) came behind an s_waitcnt vmcnt(0) -- the refill just issued had to
+    // land before the loop went on, and the second buffer bought nothing; with it the copies wait for the older refill only.
+#define CHAIN8_ENTRY(buf, i)                                                                                               \
+    {                                                                                                                      \
+        const bool fac = (i) < n_plain, pre = !fac && (i) < c;                                                             \
+        const char *bp = fac ? lcol + (long)(nb - 1 - (i)) * bstep                                                         \
+                             : (pre ? reinterpret_cast<const char *>(pmk + (long)(c - (i) - 1) * pmstep + (long)r0 * 128) : dummy); \
+        const long st = fac ? ld * 8 : (pre ? 1024 : 0);                                                                   \
+        const unsigned vo = (fac || pre) ? voff : 0u;                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
+            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * st + vo);                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
 #define CHAIN8_USE(buf, slot)                                                        \
     {                                                                                \
         const double xl = ring.xs[slot][xlane];     /* one LDS read per lane, then scalar broadcasts */ \
@@ -494,32 +441,32 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
             acc1 += buf[r].y * xr;                                                   \
         }                                                                            \
     }
-        CHAIN8_LOAD(A, 0 < n, lcol + (long)(nb - 1) * bstep, dummy);
-        CHAIN8_LOAD(B, 1 < n, lcol + (long)(nb - 2) * bstep, dummy);
-        for (int i = 0; i < n; i += 2) {
-            const int ja = nb - 1 - i;                                  // block row of A
+    const int xlane = r0 + (lane < 18 ? lane : last_row);
+    const bool xdrop = lane == 18 && nrows == 18;
+    // ---- the blocks of the factor -----------------------------------------------------------------------------------
+    if (wave == 0) {
+        for (int i = 0; i < n_plain; i++) chain_ring_put(ring, i, X + (long)(nb - 1 - i) * 128, lane);
+        CHAIN8_STAMP_T(6, 0);
+    } else {
+        CHAIN8_ENTRY(A, 0);
+        CHAIN8_ENTRY(B, 1);
+        for (int i = 0; i < n_plain; i += 2) {      // n_plain is even
             const int sa = chain_ring_get(ring, i);
             CHAIN8_USE(A, sa);
             chain_ring_done(ring, sa, lane);
-            CHAIN8_LOAD(A, i + 2 < n, lcol + (long)(ja - 2) * bstep, dummy);
-            const bool realb = i + 1 < n;
-            int sb = CH_RD;                                             // no such block: zeros
-            if (realb) sb = chain_ring_get(ring, i + 1);
+            CHAIN8_ENTRY(A, i + 2);
+            const int sb = chain_ring_get(ring, i + 1);
             CHAIN8_USE(B, sb);
-            if (realb) chain_ring_done(ring, sb, lane);
-            CHAIN8_LOAD(B, i + 3 < n, lcol + (long)(ja - 3) * bstep, dummy);
+            chain_ring_done(ring, sb, lane);
+            CHAIN8_ENTRY(B, i + 3);
         }
-#undef CHAIN8_USE
         CHAIN8_STAMP(1);
         CHAIN8_STAMP_T(7, 448);
-        CHAIN8_LOAD_PM(A, p1k);
-        CHAIN8_LOAD_PM(B, p2k);
-        q2 = chain_tail_issue(CHAIN8_TAIL_SRC(X + (long)(has2 ? k + 2 : k) * 128));     // in flight during the u-phase
-        q1 = chain_tail_issue(CHAIN8_TAIL_SRC(X + (long)(has1 ? k + 1 : k) * 128));
         red[wave][2 * lane] = acc0;
         red[wave][2 * lane + 1] = acc1;
+        acc0 = acc1 = 0.0;                          // from here on: the pre-multiplied part
     }
-    // u = W_k'(z_k - S), S over the streamed blocks
+    // ---- u = W_k'(z_k - S): t + 2 links before this workgroup's turn ----------------------------------------------------
     chain_lds_barrier();
     CHAIN8_STAMP(2);
     if (tid < 128) {
@@ -548,15 +495,30 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     double u = 0.0;
     if (tid < 128) u = (comb[0][tid] + comb[1][tid]) + (comb[2][tid] + comb[3][tid]);
     CHAIN8_STAMP(4);
-    if (has1) {
-        if (wave != 0) {
-            double p0 = 0.0, p1 = 0.0;
-            if (has2) CHAIN8_TAIL(B, q2, X + (long)(k + 2) * 128);
-            CHAIN8_TAIL(A, q1, X + (long)(k + 1) * 128);
-            CHAIN8_STAMP(5);
-            red[wave][2 * lane] = p0;
-            red[wave][2 * lane + 1] = p1;
-        }
+    // ---- the pre-multiplied blocks (at most CH_PM): from here on a link of the chain is poll -> LDS -> 38 FMAs -> LDS -> store ------
+    if (wave == 0) {
+        // (touching the pre-multiplied blocks into the L2 ahead of their loads was tried here: 0.31 -> 0.41 ms, the polls queue behind it)
+        for (int i = n_plain; i < c; i++) chain_ring_put(ring, i, X + (long)(nb - 1 - i) * 128, lane);
+    } else {
+#define CHAIN8_PRE(buf, e)                                      \
+    if ((e) < npre) {                                           \
+        const int sl = chain_ring_get(ring, n_plain + (e));     \
+        CHAIN8_USE(buf, sl);                                    \
+        chain_ring_done(ring, sl, lane);                        \
+        CHAIN8_ENTRY(buf, n_plain + (e) + 2);                   \
+    }
+        CHAIN8_PRE(A, 0);
+        CHAIN8_PRE(B, 1);
+        CHAIN8_PRE(A, 2);
+        CHAIN8_PRE(B, 3);
+        CHAIN8_PRE(A, 4);
+        static_assert(CH_PM == 5, "one CHAIN8_PRE per pre-multiplied block");
+#undef CHAIN8_PRE
+        CHAIN8_STAMP(5);
+        red[wave][2 * lane] = acc0;
+        red[wave][2 * lane + 1] = acc1;
+    }
+    if (c > 0) {
         chain_lds_barrier();
         if (tid < 128) {
             double s = 0.0;
@@ -568,14 +530,10 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     if (tid < 128) chain_publish(X + (long)k * 128 + tid, u);
 #undef CHAIN8_STAMP
 #undef CHAIN8_STAMP_T
-    if (tch == 0x7fffff17) vv[0] = 1.0;                          // keeps the touches alive
+#undef CHAIN8_USE
+#undef CHAIN8_ENTRY
     if (trace && tid == 0) trace[pos] = wall_clock64();          // JAICOV_CHAIN_TRACE: when each link was published (100 MHz)
 }
-
-#undef CHAIN8_LOAD_PM
-#undef CHAIN8_TAIL
-#undef CHAIN8_TAIL_SRC
-#undef CHAIN8_LOAD
 
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
     const int k = blockIdx.x;
@@ -616,8 +574,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMalloc(&L, sq));
     HIPCHK(hipMalloc(&invd, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
-    HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * 2 * 16384 * sizeof(double)));
-    HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * 2 * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * CH_PM * 16384 * sizeof(double)));
+    HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * CH_PM * 16384 * sizeof(double)));
     pm_ready = false;
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
 
@@ -955,20 +913,20 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
     return hipGetLastError();
 }
 
-// The two blocks below every diagonal block multiplied into its inverse, once per factorisation, for backsolve_chain8_kernel:
-// P1_k = L[k+1][k] W_k,  P2_k = L[k+2][k] W_k.  pm = [P1_0 .. P1_{nb-1}][P2_0 ..], 128 x 128 row-major each (blocks that do not
-// exist stay zero).
+// The CH_PM blocks below every diagonal block multiplied into its inverse, once per factorisation, for backsolve_chain8_kernel:
+// P_m[k] = L[k+m][k] W_k, m = 1 .. CH_PM.  pm = [P_1[0] .. P_1[nb-1]][P_2[0] ..] .., 128 x 128 row-major each (blocks that do not
+// exist stay zero).  ONE launch: batches (k, m - 1), those with k + m >= nb left out.
 hipError_t DenseSolver::premultiply() {
     if (pm_ready || !pm) return hipSuccess;
     const int nb = nfact / 128;
-    const long bstride = 128 * (ld + 1);
-    for (int m = 1; m <= 2 && m < nb; m++) {
+    if (nb > 1) {
         GemmArgs p{};
-        p.A = L + (long)m * 128 * ld; p.lda = ld; p.strideA = bstride;         // L[k+m][k]   (KC)
-        p.B = invd; p.ldb = 128; p.strideB = 16384;                           // W_k (k, j) row-major (XC)
-        p.C = pm + (size_t)(m - 1) * nb * 16384; p.ldc = 128; p.strideC = 16384;
+        p.A = L + (long)128 * ld; p.lda = ld; p.strideA = 128 * (ld + 1); p.strideA2 = (long)128 * ld;     // L[k+m][k]   (KC)
+        p.B = invd; p.ldb = 128; p.strideB = 16384; p.strideB2 = 0;                                       // W_k (k, j) row-major (XC)
+        p.C = pm; p.ldc = 128; p.strideC = 16384; p.strideC2 = (long)nb * 16384;
         p.M = p.N = p.K = 128; p.alpha = 1.0; p.beta = 0.0; p.kmode = KMODE_FULL;
-        HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, p, nb - m, 0));
+        p.batch_sum_limit = nb - 1;                 // k + (m - 1) <= nb - 2
+        HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, p, nb - 1, 0, 0, std::min(CH_PM, nb - 1)));
     }
     pm_ready = true;
     return hipGetLastError();
@@ -982,8 +940,7 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;      // the chains without pre-multiplied last blocks
     if (nrhs <= 1 && pm && !plain) {
         HIPCHK(premultiply());
-        const size_t blk = (size_t)nb * 16384;
-        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, pm + blk, rhs_row(0), X, nb, ab, (long long *)nullptr);
+        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, rhs_row(0), X, nb, ab, (long long *)nullptr);
     } else if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
@@ -1003,9 +960,8 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
         static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the backward chain on stderr
         long long *tr = nullptr;
         if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)9 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)9 * nb * sizeof(long long), stream)); }
-        const size_t blk = (size_t)nb * 16384;
         hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
-        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, pm + blk, tmp, X, nb, (const int *)nullptr, tr);
+        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, tmp, X, nb, (const int *)nullptr, tr);
         if (tracing) {
             std::vector<long long> h((size_t)9 * nb);
             HIPCHK(hipMemcpyAsync(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));

@@ -40,6 +40,8 @@ struct GemmArgs {
     int lower_only;      // square tile grid: skip tiles with tile_col > tile_row
     int kmode;           // restrict the k range per tile (triangular operands), see KMODE_*
     long strideA, strideB, strideC;  // batch strides (blockIdx.y)
+    long strideA2, strideB2, strideC2;  // second batch dimension (blockIdx.z; gridDim.z = batch2, default 1)
+    int batch_sum_limit;             // > 0: batches with blockIdx.y + blockIdx.z >= the limit do not exist (triangular batch sets)
     long long *trace;    // debug: per workgroup {start, loop begin, loop end, end} of the 100 MHz clock + hardware id
     const int2 *tile_map; // optional: workgroup -> (tile_row, tile_col), row < 0 = no tile (see xcd_tile_map)
     int n_map;            // entries of tile_map = workgroups to launch
@@ -90,9 +92,10 @@ __global__ __launch_bounds__(256, TM * TN >= 8192 ? 2 : 4) void gemm_f64_kernel(
     else if (g.kmode == KMODE_GE_ROW) kbeg = min(g.K, tile_row * GEMM_BM);
     else if (g.kmode == KMODE_GE_COL) kbeg = min(g.K, tile_col * GEMM_BN);
 
-    const double *A = g.A + (long)blockIdx.y * g.strideA;
-    const double *B = g.B + (long)blockIdx.y * g.strideB;
-    double *C = g.C + (long)blockIdx.y * g.strideC;
+    if (g.batch_sum_limit > 0 && (int)(blockIdx.y + blockIdx.z) >= g.batch_sum_limit) return;
+    const double *A = g.A + (long)blockIdx.y * g.strideA + (long)blockIdx.z * g.strideA2;
+    const double *B = g.B + (long)blockIdx.y * g.strideB + (long)blockIdx.z * g.strideB2;
+    double *C = g.C + (long)blockIdx.y * g.strideC + (long)blockIdx.z * g.strideC2;
 
     // ---- global -> register staging (8 doubles per operand per thread) -------------------------------------
     const double *ap, *bp;
@@ -284,11 +287,11 @@ inline std::vector<int2> xcd_tile_map(int T) {
 // 64-tile latency variant; `small_tiles` < 0 = that rule, 0 = never, 1 = always (rectangular KMODE_FULL calls only).
 constexpr int GEMM_SMALL_TILE_LIMIT = 480;
 constexpr int GEMM_TINY_TILE_LIMIT = 256;   // 64-tiles below which the 32-tile variant is used
-inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1, int small_tiles = -1, int tag = 0) {
+inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g, int batch = 1, int small_tiles = -1, int tag = 0, int batch2 = 1) {
     if (g.M <= 0 || g.N <= 0) return hipSuccess;
     const int tm = g.M / 128, tn = g.N / 128;
     const int tiles = g.lower_only ? tm * (tm + 1) / 2 : tm * tn;
-    dim3 grid(g.tile_map ? g.n_map : tiles, batch), block(256);
+    dim3 grid(g.tile_map ? g.n_map : tiles, batch, batch2), block(256);
     if (g.lower_only && small_tiles == 1 && g.kmode == KMODE_FULL && alay == LAY_KC && blay == LAY_KC && g.M == g.N) {
         // lower-triangular grid in 64-tiles: 4x the workgroups, a quarter of the time each.  For the trailing update of
         // the factorisation's tail, where the panel chain on the other stream waits for its workgroups to retire.
