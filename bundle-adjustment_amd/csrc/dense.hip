@@ -294,7 +294,10 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 // Same flag protocol towards the other workgroups (results preset to the all-ones pattern, relaxed agent-scope atomics), same
 // progress argument (a workgroup waits only for workgroups with a smaller index) and the same bounded spin as above.
 // What it gives at config 4 (118 links): 0.41 -> 0.31 ms, links of 2.6 us on average (1.5 - 2.1 and 2.7 - 3.9 in turn; the first
-// links of a chain, whose successors are waiting, take 1.2 - 1.5).  Steps on the way, all measured: polling wave + ring + two
+// links of a chain, whose successors are waiting, take 1.2 - 1.5).  That average is what ONE CU can stream: every workgroup reads
+// one 128 KB block per link, and 128 KB / 2.6 us = 50 GB/s is the rate a single CU reaches on this chip whatever is in flight
+// (the longest column alone, 15 MB, takes 0.3 ms).  With CH_PM = 4, 5, 6 the two-link sum stays at 5.2 - 5.4 us, only its split
+// between the two links moves.  Going below takes two CUs per block column.  Steps on the way, all measured: polling wave + ring + two
 // pre-multiplied blocks resident behind the stream 0.345 ms (the u-phase still ended after the predecessor had published);
 // every wave polling the last two results itself instead of the polling wave: no gain; touching the pre-multiplied blocks into the
 // L2 ahead of their loads: 0.41 ms (the polls queue behind the touches).  The forward chain keeps its first form: this layout
@@ -318,7 +321,10 @@ constexpr int CHAIN8_THREADS = 512;
 constexpr int CH_RD = 8;              // slots of the ring between the polling wave and the streaming waves
 constexpr int CH_SW = 7;              // streaming waves
 constexpr int CH_ROWS = 19;           // rows of a block per streaming wave: waves 1..5 take 18, waves 6 and 7 take 19
-constexpr int CH_PM = 5;              // blocks below a diagonal block that are multiplied into its inverse (DenseSolver::premultiply)
+#ifndef JAICOV_CH_PM
+#define JAICOV_CH_PM 5
+#endif
+constexpr int CH_PM = JAICOV_CH_PM;              // blocks below a diagonal block that are multiplied into its inverse (DenseSolver::premultiply)
 struct ChainRing {
     double xs[CH_RD + 1][128];        // published results, in the order of the stream; slot CH_RD: zeros (a step without a block)
     int ready[CH_RD];                 // 1 + index of the stream entry the slot holds
@@ -512,7 +518,8 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
         CHAIN8_PRE(A, 2);
         CHAIN8_PRE(B, 3);
         CHAIN8_PRE(A, 4);
-        static_assert(CH_PM == 5, "one CHAIN8_PRE per pre-multiplied block");
+        CHAIN8_PRE(B, 5);
+        static_assert(CH_PM <= 6, "one CHAIN8_PRE per pre-multiplied block");
 #undef CHAIN8_PRE
         CHAIN8_STAMP(5);
         red[wave][2 * lane] = acc0;
