@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 // links of a chain, whose successors are waiting, take 1.2 - 1.5).  That average is what ONE CU can stream: every workgroup reads
 // one 128 KB block per link, and 128 KB / 2.6 us = 50 GB/s is the rate a single CU reaches on this chip whatever is in flight
 // (the longest column alone, 15 MB, takes 0.3 ms).  With CH_PM = 4, 5, 6 the two-link sum stays at 5.2 - 5.4 us, only its split
-// between the two links moves.  Going below takes two CUs per block column.  Steps on the way, all measured: polling wave + ring + two
+// between the two links moves.  Going below takes two CUs per block column: backsolve_chain8_kernel<2>.  Steps on the way, all measured: polling wave + ring + two
 // pre-multiplied blocks resident behind the stream 0.345 ms (the u-phase still ended after the predecessor had published);
 // every wave polling the last two results itself instead of the polling wave: no gain; touching the pre-multiplied blocks into the
 // L2 ahead of their loads: 0.41 ms (the polls queue behind the touches).  The forward chain keeps its first form: this layout
@@ -320,6 +320,9 @@ __device__ __forceinline__ void chain_publish(double *dst, double v) {
 constexpr int CHAIN8_THREADS = 512;
 constexpr int CH_RD = 8;              // slots of the ring between the polling wave and the streaming waves
 constexpr int CH_SW = 7;              // streaming waves
+#ifndef CH_ROWS_LOADED
+#define CH_ROWS_LOADED 19      /* (experiment: fewer = wrong results, shows what the stream's bytes cost) */
+#endif
 constexpr int CH_ROWS = 19;           // rows of a block per streaming wave: waves 1..5 take 18, waves 6 and 7 take 19
 #ifndef JAICOV_CH_PM
 #define JAICOV_CH_PM 5
@@ -368,9 +371,18 @@ __device__ __forceinline__ void chain_ring_done(ChainRing &rg, int slot, int lan
     if (lane == 0) __hip_atomic_fetch_add(&rg.consumed[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// SPLIT = 2: workgroups 2 p and 2 p + 1 share chain position p; each streams the 64 columns of every block that belong to its 64
+// outputs (half the load instructions per link: the chain with one workgroup per column runs at what ONE CU can stream, a 128 KB
+// block per 2.6 us; loading 10 of a wave's 19 rows -- wrong results, right timing -- gave 1.05 us per link), forms its half of
+// v = z_k - S, passes it to the other through `xch` (preset to the "not published" pattern like X; once per column, several links
+// before the workgroup's turn), and publishes its half of x_k.  Used when the whole grid is resident at once (2 nb <= CUs): a
+// workgroup then also waits for its partner, which has the higher index in one of the two cases (progress: the partner is the
+// next workgroup the dispatcher starts).  0.31 -> 0.265 ms at config 4, links of 2.2 us: what is left is the way of a result from
+// the store through the successor's polling wave, ring, products and barrier to its store.
+template <int SPLIT>
 __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
                                                                           const double *__restrict__ PM, const double *__restrict__ Z,
-                                                                          double *X, int nb, const int *abort_word, long long *trace) {
+                                                                          double *X, double *xch, int nb, const int *abort_word, long long *trace) {
     __shared__ double red[8][128];
     __shared__ double comb[4][128];
     __shared__ double vv[128];
@@ -379,8 +391,10 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     if (abort_word && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int pos = blockIdx.x;                    // position in the chain
+    const int pos = SPLIT == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;          // position in the chain
+    const int half = SPLIT == 2 ? (int)(blockIdx.x & 1) : 0;                        // which 64 outputs are this workgroup's
     const int k = nb - 1 - pos;
+    if (SPLIT == 2 && half == 1) trace = nullptr;
     // The c = pos predecessors x_{k+1} .. x_{nb-1} are ONE stream, in the order they are published (x_{nb-1} first):
     //   entries 0 .. n_plain-1   blocks L[nb-1-i][k] of the factor, summed into S;  u = W_k'(z_k - S) is formed behind them,
     //   entries n_plain .. c-1   the pre-multiplied blocks P_m, m = c - i = npre .. 1, whose products go straight into x_k.
@@ -413,11 +427,19 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     __syncthreads();
     const char *lcol = reinterpret_cast<const char *>(L + (long)r0 * ld + k * 128);
     const long bstep = 128 * ld * 8;               // bytes from one block row to the next
-    const unsigned voff = 16u * (unsigned)lane;
+    // SPLIT = 1: a lane holds columns 2 lane, 2 lane + 1 of the wave's 18 / 19 rows, one row per load instruction.
+    // SPLIT = 2: a lane holds columns 64 half + 2 (lane & 31), + 1 of every second row (lanes 0..31 the even, 32..63 the odd rows of
+    //            the wave's share): TWO rows per load instruction, ten instructions per block -- what a CU can stream is set by
+    //            the number of its load instructions (lane requests), not by their bytes: 8-byte loads of 64 columns x 19 rows gave
+    //            0.27 ms, no better than the bytes of the unsplit chain would suggest.
+    constexpr int NBUF = SPLIT == 2 ? (CH_ROWS + 1) / 2 : CH_ROWS;
+    const int hr = SPLIT == 2 ? lane >> 5 : 0;                  // row parity of this lane
+    const unsigned colbytes = SPLIT == 2 ? 8u * (unsigned)(64 * half + 2 * (lane & 31)) : 16u * (unsigned)lane;
+    const bool own = SPLIT == 1 || (tid >> 6) == half;          // (of a thread tid < 128: its output is this workgroup's)
     const char *dummy = reinterpret_cast<const char *>(invd);
     const double *pmk = PM + (long)k * 16384;      // P_m of this column: pmk + (m - 1) * nb * 16384
     const long pmstep = (long)nb * 16384;
-    d2_t A[CH_ROWS], B[CH_ROWS];                   // two stream buffers; P_1 and P_2 behind the stream
+    d2_t A[NBUF], B[NBUF];                         // two stream buffers
     double acc0 = 0.0, acc1 = 0.0;                 // S (streamed blocks of the factor), then the pre-multiplied part
     // Stream entry i into a buffer: a block of the factor, a pre-multiplied block, or (past the end) nothing.  Addresses =
     // wave-uniform row base (scalar registers) + a 32-bit lane offset.  Loads past the end are issued all the same (straight-line
@@ -431,24 +453,42 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
         const char *bp = fac ? lcol + (long)(nb - 1 - (i)) * bstep                                                         \
                              : (pre ? reinterpret_cast<const char *>(pmk + (long)(c - (i) - 1) * pmstep + (long)r0 * 128) : dummy); \
         const long st = fac ? ld * 8 : (pre ? 1024 : 0);                                                                   \
-        const unsigned vo = (fac || pre) ? voff : 0u;                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++)                                                                \
-            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * st + vo);                        \
+        if (SPLIT == 2) {                                                                                                  \
+            const unsigned vo = (fac || pre) ? colbytes : 0u;                                                              \
+            _Pragma("unroll") for (int r = 0; r < NBUF; r++) {                                                             \
+                /* row 2 r + hr of the wave's share; past its end the last row again (that product is dropped: x = 0) */   \
+                const int row = 2 * r + hr < last_row ? 2 * r + hr : last_row;                                             \
+                buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)row * st + vo);                                        \
+            }                                                                                                              \
+        } else {                                                                                                           \
+            const unsigned vo = (fac || pre) ? colbytes : 0u;                                                              \
+            _Pragma("unroll") for (int r = 0; r < NBUF; r++)                                                               \
+                buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(r < 18 ? r : last_row) * st + vo);                    \
+        }                                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
     }
 #define CHAIN8_USE(buf, slot)                                                        \
     {                                                                                \
         const double xl = ring.xs[slot][xlane];     /* one LDS read per lane, then scalar broadcasts */ \
-        const double xv = xdrop ? 0.0 : xl;         /* entry 18 of a wave with 18 rows */ \
-        _Pragma("unroll") for (int r = 0; r < CH_ROWS; r++) {                        \
-            const double xr = readlane_f64(xv, r);                                   \
-            acc0 += buf[r].x * xr;                                                   \
-            acc1 += buf[r].y * xr;                                                   \
+        const double xv = xdrop ? 0.0 : xl;         /* entries past the wave's share */ \
+        if (SPLIT == 2) {                                                            \
+            _Pragma("unroll") for (int r = 0; r < NBUF; r++) {                       \
+                const double x0 = readlane_f64(xv, 2 * r), x1 = readlane_f64(xv, 2 * r + 1); \
+                const double xr = hr ? x1 : x0;                                      \
+                acc0 += buf[r].x * xr;                                               \
+                acc1 += buf[r].y * xr;                                               \
+            }                                                                        \
+        } else {                                                                     \
+            _Pragma("unroll") for (int r = 0; r < NBUF; r++) {                       \
+                const double xr = readlane_f64(xv, r);                               \
+                acc0 += buf[r].x * xr;                                               \
+                acc1 += buf[r].y * xr;                                               \
+            }                                                                        \
         }                                                                            \
     }
-    const int xlane = r0 + (lane < 18 ? lane : last_row);
-    const bool xdrop = lane == 18 && nrows == 18;
+    const int xlane = r0 + (lane < nrows ? lane : last_row);
+    const bool xdrop = lane >= nrows;               // (v_readlane indices run to 2 NBUF - 1 = 19)
     // ---- the blocks of the factor -----------------------------------------------------------------------------------
     if (wave == 0) {
         for (int i = 0; i < n_plain; i++) chain_ring_put(ring, i, X + (long)(nb - 1 - i) * 128, lane);
@@ -468,18 +508,33 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
         }
         CHAIN8_STAMP(1);
         CHAIN8_STAMP_T(7, 448);
-        red[wave][2 * lane] = acc0;
-        red[wave][2 * lane + 1] = acc1;
+        if (SPLIT == 2) {       // the two row parities of a column pair sit 32 lanes apart
+            acc0 += __shfl_xor(acc0, 32, 64);
+            acc1 += __shfl_xor(acc1, 32, 64);
+            if (lane < 32) { red[wave][64 * half + 2 * lane] = acc0; red[wave][64 * half + 2 * lane + 1] = acc1; }
+        } else { red[wave][2 * lane] = acc0; red[wave][2 * lane + 1] = acc1; }
         acc0 = acc1 = 0.0;                          // from here on: the pre-multiplied part
     }
     // ---- u = W_k'(z_k - S): t + 2 links before this workgroup's turn ----------------------------------------------------
     chain_lds_barrier();
     CHAIN8_STAMP(2);
     if (tid < 128) {
-        double s = 0.0;
+        if (own) {
+            double s = 0.0;
 #pragma unroll
-        for (int q = 1; q <= CH_SW; q++) s += red[q][tid];
-        vv[tid] = zk - s;
+            for (int q = 1; q <= CH_SW; q++) s += red[q][tid];
+            vv[tid] = zk - s;
+            if (SPLIT == 2) chain_publish(xch + (long)k * 128 + tid, zk - s);
+        } else {        // the other workgroup's half of v
+            const unsigned long long *xp = reinterpret_cast<const unsigned long long *>(xch) + (long)k * 128 + tid;
+            unsigned long long b;
+            int spin = 0;
+            do {
+                b = chain_poll(xp, spin);
+                if (b == BS_UNSET) __builtin_amdgcn_s_sleep(2);
+            } while (b == BS_UNSET && ++spin < BS_SPIN_MAX);
+            vv[tid] = __longlong_as_double((long long)b);
+        }
     }
     chain_lds_barrier();
     CHAIN8_STAMP(3);
@@ -522,19 +577,22 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
         static_assert(CH_PM <= 6, "one CHAIN8_PRE per pre-multiplied block");
 #undef CHAIN8_PRE
         CHAIN8_STAMP(5);
-        red[wave][2 * lane] = acc0;
-        red[wave][2 * lane + 1] = acc1;
+        if (SPLIT == 2) {       // the two row parities of a column pair sit 32 lanes apart
+            acc0 += __shfl_xor(acc0, 32, 64);
+            acc1 += __shfl_xor(acc1, 32, 64);
+            if (lane < 32) { red[wave][64 * half + 2 * lane] = acc0; red[wave][64 * half + 2 * lane + 1] = acc1; }
+        } else { red[wave][2 * lane] = acc0; red[wave][2 * lane + 1] = acc1; }
     }
     if (c > 0) {
         chain_lds_barrier();
-        if (tid < 128) {
+        if (tid < 128 && own) {
             double s = 0.0;
 #pragma unroll
             for (int q = 1; q <= CH_SW; q++) s += red[q][tid];
             u -= s;
         }
     }
-    if (tid < 128) chain_publish(X + (long)k * 128 + tid, u);
+    if (tid < 128 && own) chain_publish(X + (long)k * 128 + tid, u);
 #undef CHAIN8_STAMP
 #undef CHAIN8_STAMP_T
 #undef CHAIN8_USE
@@ -581,6 +639,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMalloc(&L, sq));
     HIPCHK(hipMalloc(&invd, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&xch, (size_t)nfact * sizeof(double)));
     HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * CH_PM * 16384 * sizeof(double)));
     HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * CH_PM * 16384 * sizeof(double)));
     pm_ready = false;
@@ -646,7 +705,7 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
 void DenseSolver::release() {
     if (!owns) return;
     flow_release();
-    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(pm);
+    hipFree(L); hipFree(invd); hipFree(d_info); hipFree(W); hipFree(Q); hipFree(pm); hipFree(xch);
     hipFree(tile_map_store);
     tile_map_store = nullptr;
     for (auto &kv : trtri_maps) hipFree(kv.second);
@@ -661,7 +720,7 @@ void DenseSolver::release() {
     if (dstream) hipStreamDestroy(dstream);
     pstream = ustream = dstream = nullptr;
     L = invd = W = Q = nullptr;
-    pm = nullptr; pm_ready = false;
+    pm = nullptr; pm_ready = false; xch = nullptr;
     d_info = nullptr;
     owns = false;
 }
@@ -920,6 +979,26 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
     return hipGetLastError();
 }
 
+// the backward chain for one right-hand side: two workgroups per block column when the whole grid is resident at once
+hipError_t DenseSolver::launch_chain8(const double *Zrow, double *X, const int *abort_word, long long *trace) {
+    const int nb = nfact / 128;
+    static const bool nosplit = getenv("JAICOV_CHAIN_NO_SPLIT") != nullptr;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
+        if (cus <= 0) cus = 1;
+    }
+    if (!nosplit && xch && nb >= 8 && 2 * nb <= cus) {
+        HIPCHK(hipMemsetAsync(xch, 0xFF, (size_t)nfact * sizeof(double), stream));
+        hipLaunchKernelGGL(backsolve_chain8_kernel<2>, dim3(2 * nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, Zrow, X, xch, nb, abort_word, trace);
+    } else {
+        hipLaunchKernelGGL(backsolve_chain8_kernel<1>, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, Zrow, X, xch, nb, abort_word, trace);
+    }
+    return hipGetLastError();
+}
+
 // The CH_PM blocks below every diagonal block multiplied into its inverse, once per factorisation, for backsolve_chain8_kernel:
 // P_m[k] = L[k+m][k] W_k, m = 1 .. CH_PM.  pm = [P_1[0] .. P_1[nb-1]][P_2[0] ..] .., 128 x 128 row-major each (blocks that do not
 // exist stay zero).  ONE launch: batches (k, m - 1), those with k + m >= nb left out.
@@ -947,7 +1026,7 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;      // the chains without pre-multiplied last blocks
     if (nrhs <= 1 && pm && !plain) {
         HIPCHK(premultiply());
-        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, rhs_row(0), X, nb, ab, (long long *)nullptr);
+        HIPCHK(launch_chain8(rhs_row(0), X, ab, nullptr));
     } else if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 2) hipLaunchKernelGGL(backsolve_chain_kernel<2>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
     else if (nrhs <= 4) hipLaunchKernelGGL(backsolve_chain_kernel<4>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
@@ -968,7 +1047,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
         long long *tr = nullptr;
         if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)9 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)9 * nb * sizeof(long long), stream)); }
         hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
-        hipLaunchKernelGGL(backsolve_chain8_kernel, dim3(nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, tmp, X, nb, (const int *)nullptr, tr);
+        HIPCHK(launch_chain8(tmp, X, nullptr, tr));
         if (tracing) {
             std::vector<long long> h((size_t)9 * nb);
             HIPCHK(hipMemcpyAsync(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));

@@ -4,7 +4,8 @@ The dataflow Cholesky's waits are bounded; a wait that runs out makes `solve` re
 jaicov_neq_kernel_stats()[6].  Round 2 saw one such stall per 300-3 600 factorisations until the last workgroups on the chain
 workgroups' XCDs were taken out (cholflow.hip, "keep"); 16 000 clean factorisations since.  150 passes here by default (5 s);
 JAICOV_SOAK_PASSES=4000 for a real soak (2 min).  Every pass also runs the substitution chains (dense.hip: a lost link
-would show as NaNs in the step): 14 000 passes = 28 000 launches of the polling-wave backward chain at the end of round 3, clean."""
+would show as NaNs in the step): 14 000 passes = 28 000 launches of the polling-wave backward chain at the end of round 3, and 6 000
+more with two workgroups per block column, clean."""
 import os
 
 import numpy as np
