@@ -294,7 +294,7 @@ def main():
         try:
             kr = json.load(open(os.path.join(ROOT, "bundle-adjustment_amd", "csrc", "kernel_resources.json")))
             lm = ("chol_tile_kernel<1, false>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false>", "blk_T_mfma_kernel", "blk_elim_kernel",
-                  "blk_tfix_kernel", "blk_cc", "blk_pc_gather", "rows_kernel", "backsolve_chain8_kernel", "forwardsolve_chain_kernel", "gemm_f64_kernel<0, 1, 128, 128, 0>",
+                  "blk_tfix_kernel", "blk_cc", "blk_pc_gather", "rows_kernel", "backsolve_chain8_kernel", "forwardsolve_chain8_kernel", "forwardsolve_chain_kernel", "gemm_f64_kernel<0, 1, 128, 128, 0>",
                   "symv_dd_tile_kernel", "symv_dd_reduce_kernel", "blk_backsub_kernel", "damp_and_precond_kernel")
             tab = {}
             for name, v in kr.items():

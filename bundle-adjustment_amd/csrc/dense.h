@@ -38,9 +38,10 @@ struct DenseSolver {
     const int2 *trtri_tile_order(int tm, int tn, int kind);
     double *L = nullptr;       // n x ld : input SPD matrix (lower) -> Cholesky factor (lower)
     double *invd = nullptr;    // (n/128) x 128 x 128 : inverses of the diagonal blocks of L
-    double *pm = nullptr;      // 5 x (n/128) x 128 x 128 : the backward chain's pre-multiplied blocks P_1 .. P_5 (premultiply(), dense.hip CH_PM)
+    double *pm = nullptr;      // 2 x 5 x (n/128) x 128 x 128 : the chains' pre-multiplied blocks P_1 .. P_5, Ft_1 .. Ft_5 (premultiply(), dense.hip CH_PM)
     double *xch = nullptr;     // n : the two workgroups of a block column pass their halves of v through this (backsolve_chain8_kernel<2>)
     hipError_t launch_chain8(const double *Zrow, double *X, const int *abort_word, long long *trace);
+    bool chain8_split() const;  // two workgroups per block column / row in the one-right-hand-side chains (the grid must be resident at once)
     bool pm_ready = false;     // pm belongs to the factor at hand (potrf() clears it)
     hipError_t premultiply();
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse

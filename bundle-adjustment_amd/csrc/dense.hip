@@ -600,6 +600,197 @@ __global__ __launch_bounds__(CHAIN8_THREADS) void backsolve_chain8_kernel(const 
     if (trace && tid == 0) trace[pos] = wall_clock64();          // JAICOV_CHAIN_TRACE: when each link was published (100 MHz)
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The forward chain L z = b for ONE right-hand side in the form of backsolve_chain8_kernel<2>: two workgroups per block row k, each
+// owning 64 of its 128 outputs; polling wave + ring; the blocks next to the diagonal (CH_PM or CH_PM - 1 of them) pre-multiplied,
+//     z_k = W_k (b_k - S) - sum_m Ft_m[k]' z_{k-m},   Ft_m[k] = (W_k L[k][k-m])'   (rows: index into z_{k-m}, columns: outputs),
+// and u = W_k (b_k - S) formed ahead of them.  The blocks of the factor are used as rows here (L[k][i] z_i: a workgroup streams the
+// 64 rows of its outputs, whole 1 KB rows per load instruction, 9 or 10 rows per streaming wave, one partial sum per row and lane,
+// reduced over the lanes through LDS in the u-phase); the pre-multiplied blocks as in the backward chain (64 columns, two rows per
+// load instruction).  Both kinds go through the same two buffers of ten entries.  Only launched when the whole grid is resident
+// at once (2 nb <= CUs); forwardsolve_chain_kernel otherwise.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int CHF_ROWS = 10;          // rows of a block per streaming wave in the forward chain: waves 1..6 take 9, wave 7 takes 10
+__global__ __launch_bounds__(CHAIN8_THREADS) void forwardsolve_chain8_kernel(const double *__restrict__ L, long ld, const double *__restrict__ invd,
+                                                                             const double *__restrict__ FT, const double *__restrict__ Bv,
+                                                                             double *Z, double *xch, int nb) {
+    __shared__ double red[64][65];                 // per-lane partial sums of the 64 rows; the partial sums of the pre-multiplied part ([8][128]) afterwards
+    __shared__ double part[8][64];
+    __shared__ double comb[8][64];
+    __shared__ double vv[128];
+    __shared__ double Wl[128 * 129 / 2];           // inv(L_kk), lower triangle packed by columns: (row, c) at c * 128 - c (c - 1) / 2 + (row - c)
+    __shared__ ChainRing ring;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = blockIdx.x >> 1, half = blockIdx.x & 1;      // block row = position in the chain; which 64 outputs
+    const int c = k;                               // predecessors z_0 .. z_{k-1}, published in this order: ONE stream
+    const int npre = c <= CH_PM ? c : (((c - CH_PM) & 1) ? CH_PM - 1 : CH_PM);
+    const int n_plain = c - npre;                  // entries i < n_plain: L[k][i] with z_i; then Ft_m[k], m = c - i, with z_i
+    const int di = tid & 127, h4 = tid >> 7;
+    // streaming waves 1..7, blocks of the factor: rows 64 half + r0f .. + nrf - 1 (all 128 columns: 2 lane, 2 lane + 1)
+    const int nrf = wave <= 6 ? 9 : 10, r0f = wave == 0 ? 0 : 9 * (wave - 1);
+    // pre-multiplied blocks: rows r0 .. r0 + nrows - 1 (every second one per lane half), columns 64 half + 2 (lane & 31), + 1
+    const int nrows = wave <= 5 ? 18 : 19, last_row = nrows - 1;
+    const int r0 = wave == 0 ? 0 : (wave <= 5 ? 18 * (wave - 1) : 90 + 19 * (wave - 6));
+    const int hr = lane >> 5;
+    chain_ring_init(ring, tid);
+    {
+        const double *w = invd + (long)k * 16384 + (long)di * 128 + 32 * h4;     // row di of inv(L_kk)
+        d4_t t[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) t[q] = *reinterpret_cast<const d4_t *>(w + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 32; q++) {
+            const int cc = 32 * h4 + q;
+            if (cc <= di) Wl[cc * 128 - cc * (cc - 1) / 2 + (di - cc)] = t[q >> 2][q & 3];
+        }
+    }
+    double bk = 0.0;
+    if (tid < 128) bk = Bv[k * 128 + tid];
+    __syncthreads();
+    const bool own = (tid >> 6) == half;           // (of a thread tid < 128: its output is this workgroup's)
+    const char *lrow = reinterpret_cast<const char *>(L + (long)(k * 128 + 64 * half + r0f) * ld);
+    const char *dummy = reinterpret_cast<const char *>(invd);
+    const double *ftk = FT + (long)k * 16384;      // Ft_m of this block row: ftk + (m - 1) * nb * 16384
+    const long pmstep = (long)nb * 16384;
+    const unsigned cb_fac = 16u * (unsigned)lane, cb_pre = 8u * (unsigned)(64 * half + 2 * (lane & 31));
+    d2_t A[CHF_ROWS], B[CHF_ROWS];
+    static_assert(CHF_ROWS == (CH_ROWS + 1) / 2, "one pair of buffers serves both kinds of blocks");
+    double acc[CHF_ROWS];
+#pragma unroll
+    for (int r = 0; r < CHF_ROWS; r++) acc[r] = 0.0;
+    double p0 = 0.0, p1 = 0.0;
+    // stream entry i into a buffer (see backsolve_chain8_kernel): a block of the factor (rows of this workgroup), a pre-multiplied
+    // block (columns of this workgroup), or nothing
+#define CHAINF_ENTRY(buf, i)                                                                                               \
+    {                                                                                                                      \
+        const bool fac = (i) < n_plain, pre = !fac && (i) < c;                                                             \
+        const char *bp = fac ? lrow + (long)(i) * 1024                                                                     \
+                             : (pre ? reinterpret_cast<const char *>(ftk + (long)(c - (i) - 1) * pmstep + (long)r0 * 128) : dummy); \
+        const long st = fac ? ld * 8 : (pre ? 1024 : 0);                                                                   \
+        const unsigned vo = fac ? cb_fac : (pre ? cb_pre : 0u);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int r = 0; r < CHF_ROWS; r++) {                                                             \
+            const int rf = r < nrf ? r : nrf - 1, rp = 2 * r + hr < last_row ? 2 * r + hr : last_row;                      \
+            buf[r] = *reinterpret_cast<const d2_t *>(bp + (long)(fac ? rf : rp) * st + vo);                                \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    }
+    if (wave == 0) {
+        for (int i = 0; i < n_plain; i++) chain_ring_put(ring, i, Z + (long)i * 128, lane);
+    } else {
+#define CHAINF_USE(buf, slot)                                                                                              \
+    {                                                                                                                      \
+        const d2_t z = *reinterpret_cast<const d2_t *>(&ring.xs[slot][2 * lane]);                                          \
+        _Pragma("unroll") for (int r = 0; r < CHF_ROWS; r++) acc[r] = __builtin_fma(buf[r].y, z.y, __builtin_fma(buf[r].x, z.x, acc[r])); \
+    }
+        CHAINF_ENTRY(A, 0);
+        CHAINF_ENTRY(B, 1);
+        for (int i = 0; i < n_plain; i += 2) {      // n_plain is even
+            const int sa = chain_ring_get(ring, i);
+            CHAINF_USE(A, sa);
+            chain_ring_done(ring, sa, lane);
+            CHAINF_ENTRY(A, i + 2);
+            const int sb = chain_ring_get(ring, i + 1);
+            CHAINF_USE(B, sb);
+            chain_ring_done(ring, sb, lane);
+            CHAINF_ENTRY(B, i + 3);
+        }
+#undef CHAINF_USE
+#pragma unroll
+        for (int r = 0; r < CHF_ROWS; r++)
+            if (r < nrf) red[r0f + r][lane] = acc[r];
+    }
+    // ---- u = W_k (b_k - S) for this workgroup's outputs: npre links before its turn ------------------------------------
+    chain_lds_barrier();
+    {   // row sums: thread (row, group of eight lanes)
+        const int rl = tid & 63, g = tid >> 6;
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) s += red[rl][8 * g + q];
+        part[g][rl] = s;
+    }
+    chain_lds_barrier();
+    if (tid < 128) {
+        if (own) {
+            const int rl = tid & 63;
+            const double s = ((part[0][rl] + part[1][rl]) + (part[2][rl] + part[3][rl])) + ((part[4][rl] + part[5][rl]) + (part[6][rl] + part[7][rl]));
+            vv[tid] = bk - s;
+            chain_publish(xch + (long)k * 128 + tid, bk - s);
+        } else {        // the other workgroup's half of v
+            const unsigned long long *xp = reinterpret_cast<const unsigned long long *>(xch) + (long)k * 128 + tid;
+            unsigned long long b;
+            int spin = 0;
+            do {
+                b = chain_poll(xp, spin);
+                if (b == BS_UNSET) __builtin_amdgcn_s_sleep(2);
+            } while (b == BS_UNSET && ++spin < BS_SPIN_MAX);
+            vv[tid] = __longlong_as_double((long long)b);
+        }
+    }
+    chain_lds_barrier();
+    {   // thread (output 64 half + (tid & 63), columns 16 g .. 16 g + 15)
+        const int o = 64 * half + (tid & 63), g = tid >> 6;
+        double out = 0.0;
+#pragma unroll 4
+        for (int q = 0; q < 16; q++) {
+            const int cc = 16 * g + q;
+            const double w = Wl[cc * 128 - cc * (cc - 1) / 2 + (cc <= o ? o - cc : 0)];
+            out += (cc <= o ? w : 0.0) * vv[cc];
+        }
+        comb[g][tid & 63] = out;
+    }
+    chain_lds_barrier();
+    double u = 0.0;
+    if (tid < 128 && own) {
+        const int ol = tid & 63;
+        u = ((comb[0][ol] + comb[1][ol]) + (comb[2][ol] + comb[3][ol])) + ((comb[4][ol] + comb[5][ol]) + (comb[6][ol] + comb[7][ol]));
+    }
+    // ---- the pre-multiplied blocks --------------------------------------------------------------------------------------------
+    double *red2 = &red[0][0];                     // [8][128]; every read of red[][] is three barriers back
+    if (wave == 0) {
+        for (int i = n_plain; i < c; i++) chain_ring_put(ring, i, Z + (long)i * 128, lane);
+    } else {
+        const int xlane = r0 + (lane < nrows ? lane : last_row);
+        const bool xdrop = lane >= nrows;
+#define CHAINF_PRE(buf, e)                                                                   \
+    if ((e) < npre) {                                                                        \
+        const int sl = chain_ring_get(ring, n_plain + (e));                                  \
+        const double xl = ring.xs[sl][xlane];                                                \
+        const double xv = xdrop ? 0.0 : xl;                                                  \
+        _Pragma("unroll") for (int r = 0; r < CHF_ROWS; r++) {                               \
+            const double x0 = readlane_f64(xv, 2 * r), x1 = readlane_f64(xv, 2 * r + 1);     \
+            const double xr = hr ? x1 : x0;                                                  \
+            p0 += buf[r].x * xr;                                                             \
+            p1 += buf[r].y * xr;                                                             \
+        }                                                                                    \
+        chain_ring_done(ring, sl, lane);                                                     \
+        CHAINF_ENTRY(buf, n_plain + (e) + 2);                                                \
+    }
+        CHAINF_PRE(A, 0);
+        CHAINF_PRE(B, 1);
+        CHAINF_PRE(A, 2);
+        CHAINF_PRE(B, 3);
+        CHAINF_PRE(A, 4);
+        CHAINF_PRE(B, 5);
+#undef CHAINF_PRE
+        p0 += __shfl_xor(p0, 32, 64);
+        p1 += __shfl_xor(p1, 32, 64);
+        if (lane < 32) { red2[wave * 128 + 64 * half + 2 * lane] = p0; red2[wave * 128 + 64 * half + 2 * lane + 1] = p1; }
+    }
+    if (c > 0) {
+        chain_lds_barrier();
+        if (tid < 128 && own) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 1; q <= CH_SW; q++) s += red2[q * 128 + tid];
+            u -= s;
+        }
+    }
+    if (tid < 128 && own) chain_publish(Z + (long)k * 128 + tid, u);
+#undef CHAINF_ENTRY
+}
+
 __global__ void copy_diag_blocks_kernel(const double *invd, double *W, long ld) {
     const int k = blockIdx.x;
     for (int idx = threadIdx.x; idx < 128 * 128; idx += blockDim.x) {
@@ -640,8 +831,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMalloc(&invd, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMalloc(&xch, (size_t)nfact * sizeof(double)));
-    HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * CH_PM * 16384 * sizeof(double)));
-    HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * CH_PM * 16384 * sizeof(double)));
+    HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * 2 * CH_PM * 16384 * sizeof(double)));
+    HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * 2 * CH_PM * 16384 * sizeof(double)));
     pm_ready = false;
     HIPCHK(hipMalloc(&d_info, sizeof(int)));
 
@@ -980,7 +1171,7 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
 }
 
 // the backward chain for one right-hand side: two workgroups per block column when the whole grid is resident at once
-hipError_t DenseSolver::launch_chain8(const double *Zrow, double *X, const int *abort_word, long long *trace) {
+bool DenseSolver::chain8_split() const {
     const int nb = nfact / 128;
     static const bool nosplit = getenv("JAICOV_CHAIN_NO_SPLIT") != nullptr;
     static int cus = 0;
@@ -990,7 +1181,12 @@ hipError_t DenseSolver::launch_chain8(const double *Zrow, double *X, const int *
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
         if (cus <= 0) cus = 1;
     }
-    if (!nosplit && xch && nb >= 8 && 2 * nb <= cus) {
+    return !nosplit && xch && nb >= 8 && 2 * nb <= cus;
+}
+
+hipError_t DenseSolver::launch_chain8(const double *Zrow, double *X, const int *abort_word, long long *trace) {
+    const int nb = nfact / 128;
+    if (chain8_split()) {
         HIPCHK(hipMemsetAsync(xch, 0xFF, (size_t)nfact * sizeof(double), stream));
         hipLaunchKernelGGL(backsolve_chain8_kernel<2>, dim3(2 * nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm, Zrow, X, xch, nb, abort_word, trace);
     } else {
@@ -1013,6 +1209,14 @@ hipError_t DenseSolver::premultiply() {
         p.M = p.N = p.K = 128; p.alpha = 1.0; p.beta = 0.0; p.kmode = KMODE_FULL;
         p.batch_sum_limit = nb - 1;                 // k + (m - 1) <= nb - 2
         HIPCHK(gemm_f64(stream, LAY_KC, LAY_XC, p, nb - 1, 0, 0, std::min(CH_PM, nb - 1)));
+        // Ft_m[k] = (W_k L[k][k-m])' = L[k][k-m]' W_k', k >= m: behind the P blocks, batches (k - m, m - 1)
+        GemmArgs f{};
+        f.A = L + (long)128 * ld; f.lda = ld; f.strideA = 128 * (ld + 1); f.strideA2 = (long)128 * ld;     // L[k][k-m] read transposed (XC)
+        f.B = invd + 16384; f.ldb = 128; f.strideB = 16384; f.strideB2 = 16384;                           // W_k' (kk, j) = W_k[j][kk] (KC)
+        f.C = pm + (size_t)CH_PM * nb * 16384 + 16384; f.ldc = 128; f.strideC = 16384; f.strideC2 = (long)nb * 16384 + 16384;
+        f.M = f.N = f.K = 128; f.alpha = 1.0; f.beta = 0.0; f.kmode = KMODE_FULL;
+        f.batch_sum_limit = nb - 1;
+        HIPCHK(gemm_f64(stream, LAY_XC, LAY_KC, f, nb - 1, 0, 0, std::min(CH_PM, nb - 1)));
     }
     pm_ready = true;
     return hipGetLastError();
@@ -1046,7 +1250,12 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
         static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the backward chain on stderr
         long long *tr = nullptr;
         if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)9 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)9 * nb * sizeof(long long), stream)); }
-        hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
+        if (chain8_split()) {
+            HIPCHK(hipMemsetAsync(xch, 0xFF, (size_t)nfact * sizeof(double), stream));
+            hipLaunchKernelGGL(forwardsolve_chain8_kernel, dim3(2 * nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm + (size_t)CH_PM * nb * 16384, b, tmp, xch, nb);
+        } else {
+            hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
+        }
         HIPCHK(launch_chain8(tmp, X, nullptr, tr));
         if (tracing) {
             std::vector<long long> h((size_t)9 * nb);
