@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void forwardsolve_chain_kernel(const double *_
 // between the two links moves.  Going below takes two CUs per block column: backsolve_chain8_kernel<2>.  Steps on the way, all measured: polling wave + ring + two
 // pre-multiplied blocks resident behind the stream 0.345 ms (the u-phase still ended after the predecessor had published);
 // every wave polling the last two results itself instead of the polling wave: no gain; touching the pre-multiplied blocks into the
-// L2 ahead of their loads: 0.41 ms (the polls queue behind the touches).  The forward chain keeps its first form: this layout
-// needs 19 row sums per lane there and spills.
+// L2 ahead of their loads: 0.41 ms (the polls queue behind the touches).  The forward chain has this form too where two
+// workgroups can share a block row (forwardsolve_chain8_kernel: 10 row sums per lane instead of 19, which spilled).
 // ---------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double readlane_f64(double v, int l) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
