@@ -1170,6 +1170,13 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
     return hipGetLastError();
 }
 
+// The polling-wave chains pay two batched GEMM launches per factorisation (~0.1 ms) for ~1.2 us per link and chain: from this many
+// block columns on (config 2, 6 block columns: 0.085 -> 0.14 ms per pass with them; config 3, 29: 0.28 -> 0.27)
+static int chain8_min_nb() {         // (read at every call: the tests lower it)
+    const char *e = getenv("JAICOV_CHAIN8_MIN_NB");
+    return e ? atoi(e) : 24;
+}
+
 // the backward chain for one right-hand side: two workgroups per block column when the whole grid is resident at once
 bool DenseSolver::chain8_split() const {
     const int nb = nfact / 128;
@@ -1228,7 +1235,7 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nrhs * xs * sizeof(double), stream));   // "not yet published"
     const int *ab = flow_ready ? flow_flags + 1 : nullptr;      // cholflow.hip FLOW_ABORT
     static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;      // the chains without pre-multiplied last blocks
-    if (nrhs <= 1 && pm && !plain) {
+    if (nrhs <= 1 && pm && !plain && nb >= chain8_min_nb()) {
         HIPCHK(premultiply());
         HIPCHK(launch_chain8(rhs_row(0), X, ab, nullptr));
     } else if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
@@ -1245,7 +1252,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
     HIPCHK(hipMemsetAsync(tmp, 0xFF, (size_t)nfact * sizeof(double), stream));
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nfact * sizeof(double), stream));
     static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;
-    if (pm && !plain) {
+    if (pm && !plain && nb >= chain8_min_nb()) {
         HIPCHK(premultiply());
         static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the backward chain on stderr
         long long *tr = nullptr;

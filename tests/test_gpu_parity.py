@@ -56,10 +56,12 @@ def test_dense_spd_solve_and_inverse(n):
 
 
 @pytest.mark.parametrize("n", [100, 200, 384, 500, 640, 1100, 2100, 4200])
-def test_dense_spd_solve_one_right_hand_side(n):
-    """ONE right-hand side takes the polling-wave form of the backward chain (backsolve_chain8_kernel, dense.hip): 1, 2, 3, 4, 5, 9, 17
-    and 33 block columns -- no predecessor, one and two pre-multiplied blocks only, streams of odd and even length, and streams
-    longer than the ring between the polling wave and the streaming waves (8 slots)."""
+def test_dense_spd_solve_one_right_hand_side(n, monkeypatch):
+    """ONE right-hand side takes the polling-wave form of the backward chain (backsolve_chain8_kernel, dense.hip; by default from 24
+    block columns on, here from one): 1, 2, 3, 4, 5, 9, 17 and 33 block columns -- no predecessor, fewer predecessors than
+    pre-multiplied blocks, streams of odd and even length, one and two workgroups per block column, and streams longer than the ring
+    between the polling wave and the streaming waves (8 slots)."""
+    monkeypatch.setenv("JAICOV_CHAIN8_MIN_NB", "1")
     rng = np.random.default_rng(7 * n)
     G = rng.normal(size=(n, n + 20))
     S = G @ G.T / n + np.eye(n)

@@ -46,8 +46,11 @@ def rel(a, b):
     return float(np.abs(a - b).max() / np.abs(b).max())
 
 
+@pytest.mark.parametrize("chains", ["default", "polling_wave_from_one_block_column"])
 @pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free", "mid_block", "cfg3"])
-def test_refined_step_is_the_exact_solution_of_the_assembled_system(oracle_mod, name):
+def test_refined_step_is_the_exact_solution_of_the_assembled_system(oracle_mod, name, chains, monkeypatch):
+    if chains != "default":         # dense.hip: the one-right-hand-side chains in their polling-wave form, by default from 24 block columns on
+        monkeypatch.setenv("JAICOV_CHAIN8_MIN_NB", "1")
     fp = (scene.make_scene(12, 150, 90, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
           if name == "mid_block" else scene.config(name))
     s2, U, d = fp.sigma2apriori, fp.n_unknowns, fp.rank_defect
