@@ -320,9 +320,6 @@ __device__ __forceinline__ void chain_publish(double *dst, double v) {
 constexpr int CHAIN8_THREADS = 512;
 constexpr int CH_RD = 8;              // slots of the ring between the polling wave and the streaming waves
 constexpr int CH_SW = 7;              // streaming waves
-#ifndef CH_ROWS_LOADED
-#define CH_ROWS_LOADED 19      /* (experiment: fewer = wrong results, shows what the stream's bytes cost) */
-#endif
 constexpr int CH_ROWS = 19;           // rows of a block per streaming wave: waves 1..5 take 18, waves 6 and 7 take 19
 #ifndef JAICOV_CH_PM
 #define JAICOV_CH_PM 5
