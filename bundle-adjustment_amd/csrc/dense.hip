@@ -326,13 +326,12 @@ constexpr int CH_ROWS = 19;           // rows of a block per streaming wave: wav
 #endif
 constexpr int CH_PM = JAICOV_CH_PM;              // blocks below a diagonal block that are multiplied into its inverse (DenseSolver::premultiply)
 struct ChainRing {
-    double xs[CH_RD + 1][128];        // published results, in the order of the stream; slot CH_RD: zeros (a step without a block)
+    double xs[CH_RD][128];            // published results, in the order of the stream
     int ready[CH_RD];                 // 1 + index of the stream entry the slot holds
     int consumed[CH_RD];              // streaming waves that are done with the slot, counted over all its uses
 };
 __device__ __forceinline__ void chain_ring_init(ChainRing &rg, int tid) {
     if (tid < CH_RD) { rg.ready[tid] = 0; rg.consumed[tid] = 0; }
-    if (tid < 128) rg.xs[CH_RD][tid] = 0.0;
 }
 // A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every global load in flight (s_waitcnt
 // vmcnt(0)): behind the stream those are the two pre-multiplied blocks and the first polls for the predecessors' results, which
