@@ -43,6 +43,8 @@ struct DenseSolver {
     hipError_t launch_chain8(const double *Zrow, double *X, const int *abort_word, long long *trace);
     bool chain8_split() const;  // two workgroups per block column / row in the one-right-hand-side chains (the grid must be resident at once)
     bool pm_ready = false;     // pm belongs to the factor at hand (potrf() clears it)
+    hipEvent_t pm_e0 = nullptr, pm_done = nullptr;   // the Ft half of premultiply() runs on pstream
+    bool pm_wait = false;      // ... and `stream` has not waited for it yet
     hipError_t premultiply();
     double *W = nullptr;       // n x ld : L^-1 (lower), only for the inverse
     double *Q = nullptr;       // n x ld : (L L')^-1 (lower tiles valid; symmetrize() fills the rest); workspace of trtri()

@@ -827,6 +827,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     HIPCHK(hipMalloc(&invd, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMemset(invd, 0, (size_t)(nfact / 128) * 16384 * sizeof(double)));
     HIPCHK(hipMalloc(&xch, (size_t)nfact * sizeof(double)));
+    HIPCHK(hipEventCreateWithFlags(&pm_e0, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&pm_done, hipEventDisableTiming));
     HIPCHK(hipMalloc(&pm, (size_t)(nfact / 128) * 2 * CH_PM * 16384 * sizeof(double)));
     HIPCHK(hipMemset(pm, 0, (size_t)(nfact / 128) * 2 * CH_PM * 16384 * sizeof(double)));
     pm_ready = false;
@@ -907,6 +909,9 @@ void DenseSolver::release() {
     if (dstream) hipStreamDestroy(dstream);
     pstream = ustream = dstream = nullptr;
     L = invd = W = Q = nullptr;
+    if (pm_e0) hipEventDestroy(pm_e0);
+    if (pm_done) hipEventDestroy(pm_done);
+    pm_e0 = pm_done = nullptr; pm_wait = false;
     pm = nullptr; pm_ready = false; xch = nullptr;
     d_info = nullptr;
     owns = false;
@@ -1011,6 +1016,7 @@ int DenseSolver::first_panel_cols() const {
 
 hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
     pm_ready = false;
+    if (pm_wait) { HIPCHK(hipStreamWaitEvent(stream, pm_done, 0)); pm_wait = false; }      // the side stream still reads the old factor
     if (flow_ready) return potrf_flow(all_ready);
     return potrf_streams(first_ready, all_ready);
 }
@@ -1219,7 +1225,18 @@ hipError_t DenseSolver::premultiply() {
         f.C = pm + (size_t)CH_PM * nb * 16384 + 16384; f.ldc = 128; f.strideC = 16384; f.strideC2 = (long)nb * 16384 + 16384;
         f.M = f.N = f.K = 128; f.alpha = 1.0; f.beta = 0.0; f.kmode = KMODE_FULL;
         f.batch_sum_limit = nb - 1;
-        HIPCHK(gemm_f64(stream, LAY_XC, LAY_KC, f, nb - 1, 0, 0, std::min(CH_PM, nb - 1)));
+        // the Ft blocks are needed by the forward chain of the refinement only: on the side stream, beside the first backward chain
+        // and the residual (solve_rhs waits for pm_done)
+        static const bool side = !getenv("JAICOV_PM_ONE_STREAM");
+        if (side && pstream && pm_e0 && pm_done) {
+            HIPCHK(hipEventRecord(pm_e0, stream));
+            HIPCHK(hipStreamWaitEvent(pstream, pm_e0, 0));
+            HIPCHK(gemm_f64(pstream, LAY_XC, LAY_KC, f, nb - 1, 0, 0, std::min(CH_PM, nb - 1)));
+            HIPCHK(hipEventRecord(pm_done, pstream));
+            pm_wait = true;
+        } else {
+            HIPCHK(gemm_f64(stream, LAY_XC, LAY_KC, f, nb - 1, 0, 0, std::min(CH_PM, nb - 1)));
+        }
     }
     pm_ready = true;
     return hipGetLastError();
@@ -1253,6 +1270,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
         static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the backward chain on stderr
         long long *tr = nullptr;
         if (tracing) { HIPCHK(hipMalloc(&tr, (size_t)9 * nb * sizeof(long long))); HIPCHK(hipMemsetAsync(tr, 0, (size_t)9 * nb * sizeof(long long), stream)); }
+        if (pm_wait) { HIPCHK(hipStreamWaitEvent(stream, pm_done, 0)); pm_wait = false; }
         if (chain8_split()) {
             HIPCHK(hipMemsetAsync(xch, 0xFF, (size_t)nfact * sizeof(double), stream));
             hipLaunchKernelGGL(forwardsolve_chain8_kernel, dim3(2 * nb), dim3(CHAIN8_THREADS), 0, stream, L, ld, invd, pm + (size_t)CH_PM * nb * 16384, b, tmp, xch, nb);
