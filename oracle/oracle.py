@@ -32,7 +32,8 @@ class OracleResult(C.Structure):
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libba_oracle.so")
     src = os.path.join(_HERE, "ba_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "ba_exact.c")))
+    if force or not os.path.exists(so) or os.path.getmtime(so) < newest:
         subprocess.check_call(["make", "-C", _HERE, "-B", "libba_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -74,6 +75,15 @@ def lib():
         L.oracle_faithful_image_points.restype = C.c_double
         L.oracle_block_weight.argtypes = [P, C.c_double, C.c_int, _pd]
         L.oracle_block_fair.argtypes = [P, _pd, C.c_double, C.c_int, _pd, _pd, _pd]
+        # ba_exact.c: extended-precision ground truth (NOT the reference's arithmetic; accuracy study only)
+        L.oracle_exact_accumulate.argtypes = [P, _pd, C.c_double, _pd, _pd, _pd, _pd]
+        L.oracle_exact_block_weight.argtypes = [P, C.c_double, C.c_int, _pd, _pd]
+        L.oracle_inverse_residual_q.argtypes = [C.c_int, _pd, _pd, _pd, C.c_double, C.c_int, C.c_int]
+        L.oracle_inverse_residual_q.restype = C.c_double
+        L.oracle_residual_ld2.argtypes = [C.c_int, _pd, _pd, C.c_int, _pd, _pd, _pd, _pd]
+        L.oracle_residual_ld2.restype = None
+        L.oracle_matvec_ld2.argtypes = [C.c_int, _pd, _pd, _pd, _pd]
+        L.oracle_matvec_ld2.restype = None
         _LIB = L
     return _LIB
 
@@ -197,6 +207,26 @@ class Oracle:
     def block_fair(self, values, sigma2, blk, Pm, N, n):
         v = _f(values)
         return self.L.oracle_block_fair(C.byref(self.desc), _p(v), sigma2, blk, _p(Pm), _p(N), _p(n))
+
+    # ---- extended-precision ground truth (ba_exact.c) ----------------------------------------------------------
+    def exact_accumulate(self, values, sigma2):
+        """N, n of all observation groups with P = sigma0^2 inv(D) and every sum in x87 extended precision, each rounded once
+        to a (hi, lo) pair: returns N_hi, N_lo, n_hi, n_lo (packed 'U')."""
+        v = _f(values)
+        Nh = np.zeros(self.fp.packed_length); Nl = np.zeros(self.fp.packed_length)
+        nh = np.zeros(self.U); nl = np.zeros(self.U)
+        info = self.L.oracle_exact_accumulate(C.byref(self.desc), _p(v), sigma2, _p(Nh), _p(Nl), _p(nh), _p(nl))
+        if info:
+            raise ArithmeticError(f"oracle_exact_accumulate info={info}")
+        return Nh, Nl, nh, nl
+
+    def exact_block_weight(self, sigma2, blk):
+        m = 2 * int(self.fp.blk_ip_begin[blk + 1] - self.fp.blk_ip_begin[blk])
+        Ph = np.zeros((m, m)); Pl = np.zeros((m, m))
+        info = self.L.oracle_exact_block_weight(C.byref(self.desc), sigma2, blk, _p(Ph), _p(Pl))
+        if info:
+            raise ArithmeticError(f"oracle_exact_block_weight info={info}")
+        return Ph, Pl
 
     def faithful_image_points(self, values, sigma2, ip_begin, ip_end, N, n):
         v = _f(values)
