@@ -934,6 +934,8 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
                                   double *cc_partial, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (n_list <= 0) return hipSuccess;
     const int schur = sb.active ? 1 : 0;
+    // the fused gather (P' formed in registers) reads U_q from the coalesced copy Ug only: there is no row-major fallback
+    if (schur && !sb.materialise && pp.pt_ip_begin && !pp.ug) return hipErrorInvalidValue;
     const bool t_vector = getenv("JAICOV_T_VECTOR") != nullptr;
     if (t_vector) hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
     else hipLaunchKernelGGL(blk_T_mfma_kernel, dim3((max_m + 255) / 256, n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T);

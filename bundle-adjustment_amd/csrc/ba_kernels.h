@@ -61,7 +61,8 @@ struct PPGather {
     const int32_t *range = nullptr;
     int cmin = 0, n_chunks = 0;
     int cw = PP_CW;            // columns of one LDS strip (runtime: JAICOV_PP_CW; multiple of 4, the LDS strip is 3 * cw doubles)
-    const double *ug = nullptr; // SchurBufs::Ug (coalesced U_q loads) or null: read U_q from the row-major U buffer
+    const double *ug = nullptr; // SchurBufs::Ug (coalesced U_q loads): REQUIRED when the gather forms P' = sigma2 Dinv - U U' itself (EO pre-elimination
+                                // without SchurBufs::materialise); launch_assemble_blocks refuses the launch otherwise
     int xcd_map = 0;           // != 0: 1-D grid, every XCD works on its own chunks only (blk_pp_gather_kernel)
     // plain != 0: the rows cmin..cmax of N are point rows only and nobody else has written their columns >= cmin yet;
     // the strips are then STORED (zeros included) instead of added, which saves zeroing that part of N and reading it back
@@ -73,7 +74,8 @@ struct PPGather {
 // buffers of the per-image EO pre-elimination (schur.hip); Pp == nullptr -> mode off
 struct SchurBufs {
     double *U = nullptr, *Linv = nullptr, *G = nullptr, *Pp = nullptr, *diagcorr = nullptr;
-    double *Ug = nullptr;     // the same U once more, laid out for the point x point gather: [6][n_ip] pairs (see blk_elim_kernel); may be null
+    double *Ug = nullptr;     // the same U once more, laid out for the point x point gather: [6][n_ip] pairs (see blk_elim_kernel); blk_elim_kernel
+                              // skips it when null, the fused gather needs it (PPGather::ug)
     double *xq = nullptr;     // [6 * images] n_E / diag(N_EE): what the reference's REDUCED last pass leaves in dx (engine option)
     int *info = nullptr;
     double lambda = 0.0;

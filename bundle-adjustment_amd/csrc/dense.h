@@ -100,6 +100,7 @@ struct DenseSolver {
     // columns [0, first_panel_cols()) resp. the whole matrix are in place -- the first panel then factors while the
     // caller is still filling the rest.
     hipError_t potrf(hipEvent_t first_ready = nullptr, hipEvent_t all_ready = nullptr);
+    hipError_t begin_refactor();                            // before the first write into L for a new factorisation (waits for the side stream's readers of the old one)
     int first_panel_cols() const;
     hipError_t backsolve_aug(double *X, long xs, int nrhs);  // L' X = Z, Z = the rhs rows after potrf(); X rows have stride xs
     hipError_t solve_rhs(const double *b, double *tmp, double *X);   // X = (L L')^-1 b, one right-hand side (forward + backward chain)

@@ -356,11 +356,14 @@ __device__ __forceinline__ void chain_ring_put(ChainRing &rg, int i, const doubl
     rg.xs[slot][lane + 64] = __longlong_as_double((long long)b1);
     __hip_atomic_store(&rg.ready[slot], i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // one wave: every lane writes the same word
 }
-// a streaming wave: waits for entry i, returns its slot
+// a streaming wave: waits for entry i, returns its slot.  No time limit of its own: the polling wave's waits are the bounded
+// ones (chain_ring_put gives up on a lost predecessor after BS_SPIN_MAX polls and hands over the "not published" pattern, a NaN),
+// and it sets `ready` for every entry whatever happened, so this loop ends whenever that one does -- and a predecessor that is
+// merely LATE is waited for as long as the polling wave waits, instead of being replaced by stale ring contents after a shorter
+// spin of this wave's own (a finite but wrong x_k; the tests rely on a lost link showing up as NaNs).
 __device__ __forceinline__ int chain_ring_get(ChainRing &rg, int i) {
     const int slot = i & (CH_RD - 1);
-    int spin = 0;
-    while (__hip_atomic_load(&rg.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != i + 1 && ++spin < BS_SPIN_MAX) __builtin_amdgcn_s_sleep(0);
+    while (__hip_atomic_load(&rg.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != i + 1) __builtin_amdgcn_s_sleep(0);
     return slot;
 }
 __device__ __forceinline__ void chain_ring_done(ChainRing &rg, int slot, int lane) {
@@ -1014,9 +1017,17 @@ int DenseSolver::first_panel_cols() const {
     return 128 * (k < nb ? k : nb);
 }
 
-hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
+// Call before the first WRITE into L for a new factorisation (the engine's scaled copy, a dispersion load): the Ft half of the last
+// premultiply() may still be reading the old factor on pstream.  potrf() does the same for callers that fill L through potrf's own
+// first tile load (flow_set_source), where nothing writes L earlier.
+hipError_t DenseSolver::begin_refactor() {
     pm_ready = false;
-    if (pm_wait) { HIPCHK(hipStreamWaitEvent(stream, pm_done, 0)); pm_wait = false; }      // the side stream still reads the old factor
+    if (pm_wait) { HIPCHK(hipStreamWaitEvent(stream, pm_done, 0)); pm_wait = false; }
+    return hipSuccess;
+}
+
+hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
+    HIPCHK(begin_refactor());
     if (flow_ready) return potrf_flow(all_ready);
     return potrf_streams(first_ready, all_ready);
 }
@@ -1277,7 +1288,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
         } else {
             hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
         }
-        HIPCHK(launch_chain8(tmp, X, nullptr, tr));
+        HIPCHK(launch_chain8(tmp, X, flow_ready ? flow_flags + 1 : nullptr, tr));   // behind an abandoned factorisation: leave at once (as backsolve_aug)
         if (tracing) {
             std::vector<long long> h((size_t)9 * nb);
             HIPCHK(hipMemcpyAsync(h.data(), tr, h.size() * sizeof(long long), hipMemcpyDeviceToHost, stream));
@@ -1295,7 +1306,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
         return hipGetLastError();
     }
     hipLaunchKernelGGL(forwardsolve_chain_kernel, dim3(nb), dim3(256), 0, stream, L, ld, invd, b, tmp, nb);
-    hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, tmp, (long)nfact, X, (long)nfact, nb, 1, (const int *)nullptr);
+    hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, tmp, (long)nfact, X, (long)nfact, nb, 1, flow_ready ? flow_flags + 1 : (const int *)nullptr);
     return hipGetLastError();
 }
 

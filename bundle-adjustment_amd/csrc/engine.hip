@@ -15,6 +15,7 @@
 #include "../../include/jaicov_dense.h"
 #include "../../include/jaicov_neq.h"
 #include "ba_kernels.h"
+#include "batchinv.h"
 #include "dense.h"
 #include "gemm_f64.h"
 
@@ -231,6 +232,12 @@ struct jaicov_engine {
     int q_order = 0;                 // order of the cofactor matrix on the device (U, or e0 for the reduced one)
     bool q_reduced = false, solverS_has_inverse = false;
     std::vector<int> h_blk_images;   // image of every block handled by this engine
+    std::vector<int32_t> h_caller_block; // internal image block -> the caller's block index (-1: an ordinary image served as a block); empty: identity
+    bool synthesized_blocks = false;     // ordinary image groups are served as image blocks with block-diagonal weights (create_impl)
+    std::vector<int32_t> h_perm_local;   // per image point of a dense block: engine position -> caller's position inside the block (empty: identity)
+    std::vector<int64_t> h_blk_w_off;    // offset of every image block's weight in p.blk_w
+    std::vector<int32_t> h_blk_ip_begin; // copy of blk_ip_begin
+    std::vector<uint8_t> h_blk_mine;     // this engine holds the block's weight
     std::vector<int32_t> ip_old2new; // empty, or: engine position of the caller's observation (dense blocks are column-sorted)
     int e0 = 0;                   // first EO column == order of the reduced system
     SchurBufs sb;
@@ -256,6 +263,7 @@ struct jaicov_engine {
     double lambda_used = 0.0;
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    double create_ms[4] = {0, 0, 0, 0};   // jaicov_neq_create: [0] whole call, [1] host time in the dispersion uploads, [2] dispersions -> weights (wall), [3] spare
     hipEvent_t ev[10];
     bool pp_plain_ok = false;   // the point x point gather may store its strips (see PPGather::plain)
     hipEvent_t ev_first = nullptr, ev_all = nullptr;   // solve(): first panel's columns / whole matrix copied into the solver
@@ -309,27 +317,125 @@ static int check_device(std::string &err) {
     return JAICOV_OK;
 }
 
-// inverse of a dense SPD dispersion on the device: out (m x m row-major, device) = D^-1
-static int invert_dispersion(jaicov_engine *e, DenseSolver &ds, const double *d_D, int m, double *d_out,
-                             const int32_t *d_perm = nullptr) {
-    const int mp = ds.n;
-    int info = 0;
-    for (int attempt = 0;; attempt++) {      // an abandoned dataflow factorisation (-9; orders >= 24 block columns) is repeated: d_D is untouched
-        hipLaunchKernelGGL(load_disp_kernel, dim3((mp + 255) / 256, mp), dim3(256), 0, e->stream, d_D, m, ds.L, ds.ld, mp, d_perm);
-        HIPE(e, ds.potrf());
-        HIPE(e, ds.trtri());                 // enqueued behind the factorisation whatever its outcome: ONE host round trip per matrix
-        HIPE(e, ds.lauum());
-        hipLaunchKernelGGL(store_inv_kernel, dim3((m + 255) / 256, m), dim3(256), 0, e->stream, ds.Q, ds.ld, m, d_out);
-        info = ds.fetch_info();
-        if (info == -9 && attempt < 2) {
-            ++e->flow_retries;
-            fprintf(stderr, "jaicov: factorisation of a dispersion matrix abandoned on the device (a wait ran into its time limit); repeating it (%d)\n", attempt + 1);
-            continue;
-        }
-        break;
+// ---- dense dispersions -> weights, all groups of one padded order together (batchinv.hip) ------------------------------------
+struct DispItem { const double *host; double *dst; const int32_t *perm; int m; };   // dst, perm: device pointers
+struct DispDesc { const double *src; double *dst; const int32_t *perm; int m; int pad; };
+// dense dispersion (row-major m x m, in the staging buffer) -> padded square with identity padding, in the engine's point order
+// perm (optional): engine point position -> caller's point position inside the block (rows 2q, 2q+1 move together)
+__global__ void load_disp_batched_kernel(const DispDesc *__restrict__ desc, double *__restrict__ Lb, double *__restrict__ Db, long ld, long msz, int mp) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j >= mp) return;
+    const DispDesc dd = desc[blockIdx.z];
+    double v = (i == j) ? 1.0 : 0.0;
+    if (i < dd.m && j < dd.m) {
+        const int si = dd.perm ? 2 * dd.perm[i >> 1] + (i & 1) : i, sj = dd.perm ? 2 * dd.perm[j >> 1] + (j & 1) : j;
+        v = dd.src[(long)si * dd.m + sj];
     }
-    if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation of a dispersion matrix did not complete on the device (code " + std::to_string(info) + ")");
-    if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)");
+    Lb[(long)blockIdx.z * msz + (long)i * ld + j] = v;
+    if (Db) Db[(long)blockIdx.z * msz + (long)i * ld + j] = v;      // the refinement of the inverse reads the matrix once more
+}
+__global__ void store_inv_batched_kernel(const DispDesc *__restrict__ desc, const double *__restrict__ Qb, long ld, long msz) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    const DispDesc dd = desc[blockIdx.z];
+    if (i >= dd.m || j >= dd.m) return;
+    dd.dst[(long)i * dd.m + j] = Qb[(long)blockIdx.z * msz + (long)i * ld + j];
+}
+
+// inv(D) of an ordinary image served as a block: 2 x 2 blocks [[vx, rho s], [rho s, vy]]^-1, s = sqrt(vx vy), on the diagonal
+// (PDF:313-319 divided by sigma0^2; rho == 0: 1 / vx, 1 / vy as PDF:308-312), zeros elsewhere.  One workgroup per row.
+__global__ void fill_diag_weight_kernel(const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ rho, int ipb, int m,
+                                        double *__restrict__ out) {
+    const int i = blockIdx.x, q = i >> 1, r = i & 1;
+    const double x = vx[ipb + q], y = vy[ipb + q], c = rho[ipb + q];
+    double w0, w1;   // entries (i, 2q), (i, 2q + 1)
+    if (c == 0.0) { w0 = r == 0 ? 1.0 / x : 0.0; w1 = r == 0 ? 0.0 : 1.0 / y; }
+    else {
+        const double inv_det = 1.0 / ((1.0 - c * c) * x * y), off = -inv_det * c * sqrt(x * y);
+        w0 = r == 0 ? inv_det * y : off;
+        w1 = r == 0 ? off : inv_det * x;
+    }
+    double *o = out + (long)i * m;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) o[j] = j == 2 * q ? w0 : (j == 2 * q + 1 ? w1 : 0.0);
+}
+
+// DOPG:82-86 for every jointly dispersed group of the problem: items of one padded order are inverted in chunks (one set of
+// batched launches per chunk); the upload of chunk c + 1 runs on a copy stream beside the inversion of chunk c.
+// Timings (ms) are left in e->create_ms: [1] host time spent in the uploads, [2] everything (wall).
+static int invert_dispersions(jaicov_engine *e, std::vector<DispItem> &items) {
+    if (items.empty()) return JAICOV_OK;
+    const auto t_all = std::chrono::steady_clock::now();
+    double up_ms = 0.0;
+    std::stable_sort(items.begin(), items.end(), [](const DispItem &a, const DispItem &b) { return (a.m + 127) / 128 < (b.m + 127) / 128; });
+    hipStream_t cstream = nullptr;
+    HIPE(e, hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; b++) {
+        HIPE(e, hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming));
+        HIPE(e, hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming));
+    }
+    int status = JAICOV_OK;
+    std::string msg;
+    for (size_t g0 = 0; g0 < items.size() && status == JAICOV_OK;) {
+        const int mp = ((items[g0].m + 127) / 128) * 128;
+        size_t g1 = g0;
+        int mmax = 0;
+        while (g1 < items.size() && ((items[g1].m + 127) / 128) * 128 == mp) { mmax = std::max(mmax, items[g1].m); g1++; }
+        const int count = (int)(g1 - g0);
+        const size_t msz = (size_t)mp * mp, mm = (size_t)mmax * mmax;
+        // chunk: <= 64 matrices and <= ~4 GB of workspace (3 squares per matrix, 6 with the refinement) -- 8 chunks at config 4, the first upload (0.5 GB)
+        // is the only one that nothing overlaps
+        const bool refine = e->opts.dispersion_refinement >= 0;
+        int cap = (int)std::max<size_t>(1, std::min<size_t>(64, ((size_t)4 << 30) / ((refine ? 6 : 3) * msz * sizeof(double))));
+        cap = std::min(cap, count);
+        BatchedSpdInverse bi;
+        double *d_stage[2] = {nullptr, nullptr};
+        DispDesc *d_desc = nullptr;
+        std::vector<DispDesc> desc(count);
+        hipError_t he = bi.init(e->stream, mp, cap, refine);
+        for (int b = 0; b < 2 && he == hipSuccess; b++) he = hipMalloc(&d_stage[b], (size_t)cap * mm * sizeof(double));
+        if (he == hipSuccess) he = hipMalloc(&d_desc, (size_t)count * sizeof(DispDesc));
+        if (he == hipSuccess) {
+            for (int t = 0; t < count; t++) {
+                const int c = t / cap, b = c & 1;
+                desc[t] = DispDesc{d_stage[b] + (size_t)(t - c * cap) * mm, items[g0 + t].dst, items[g0 + t].perm, items[g0 + t].m, 0};
+            }
+            he = hipMemcpyAsync(d_desc, desc.data(), (size_t)count * sizeof(DispDesc), hipMemcpyHostToDevice, e->stream);
+        }
+        for (int c = 0; he == hipSuccess && c * cap < count; c++) {
+            const int b = c & 1, first = c * cap, cnt = std::min(cap, count - first);
+            if (c >= 2) he = hipStreamWaitEvent(cstream, ev_free[b], 0);      // the load kernel of chunk c - 2 has consumed this buffer
+            const auto t_up = std::chrono::steady_clock::now();
+            for (int t = 0; t < cnt && he == hipSuccess; t++) {
+                const DispItem &it = items[g0 + first + t];
+                he = hipMemcpyAsync(d_stage[b] + (size_t)t * mm, it.host, (size_t)it.m * it.m * sizeof(double), hipMemcpyHostToDevice, cstream);
+            }
+            up_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_up).count();
+            if (he == hipSuccess) he = hipEventRecord(ev_up[b], cstream);
+            if (he == hipSuccess) he = hipStreamWaitEvent(e->stream, ev_up[b], 0);
+            if (he != hipSuccess) break;
+            hipLaunchKernelGGL(load_disp_batched_kernel, dim3((mp + 255) / 256, mp, cnt), dim3(256), 0, e->stream, d_desc + first, bi.Lb, bi.refine ? bi.Db : (double *)nullptr, bi.ld, bi.msz, mp);
+            he = hipEventRecord(ev_free[b], e->stream);
+            if (he == hipSuccess) he = bi.run(cnt);
+            if (he != hipSuccess) break;
+            hipLaunchKernelGGL(store_inv_batched_kernel, dim3((mmax + 255) / 256, mmax, cnt), dim3(256), 0, e->stream, d_desc + first, bi.Qb, bi.ld, bi.msz);
+        }
+        int info = 0;
+        if (he == hipSuccess) he = hipMemcpyAsync(&info, bi.d_info, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        hipStreamSynchronize(cstream);
+        bi.release();
+        hipFree(d_stage[0]); hipFree(d_stage[1]); hipFree(d_desc);
+        if (he != hipSuccess) { status = he == hipErrorOutOfMemory ? JAICOV_ERR_OUT_OF_MEMORY : JAICOV_ERR_DEVICE; msg = std::string("inversion of the dispersion matrices: ") + hipGetErrorString(he); }
+        else if (info != 0) { status = JAICOV_ERR_SINGULAR; msg = "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)"; }
+        g0 = g1;
+    }
+    for (int b = 0; b < 2; b++) { hipEventDestroy(ev_up[b]); hipEventDestroy(ev_free[b]); }
+    hipStreamDestroy(cstream);
+    e->create_ms[1] = up_ms;
+    e->create_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count();
+    if (status != JAICOV_OK) FAIL(e, status, msg);
     return JAICOV_OK;
 }
 
@@ -435,6 +541,66 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
         const int32_t *en = std::lower_bound(D->ip_image, D->ip_image + D->n_image_points, ie);
         e->ip0 = (int)(b - D->ip_image);
         e->ip_count = (int)(en - b);
+    }
+    // ---- ordinary image groups as jointly dispersed groups with a block-diagonal weight ----------------------------------
+    // reduceNormalEquationSystem (BA:1197-1342) eliminates the exterior orientation of EVERY image, whatever its stochastic
+    // model; the device path of that elimination (schur.hip) is written for image groups with a joint weight matrix.  An image
+    // whose points are ordinary ImageCoordinate groups (diagonal / 2 x 2 weights, PDF:296-319) is the special case of a
+    // block-diagonal joint weight: when the whole problem qualifies, every such image becomes an internal image block whose
+    // inv(D) is filled from (var_x, var_y, rho) in closed form -- no dispersion is uploaded or inverted -- and the
+    // elimination, the point x point gather and the reduced solve serve it like any other block.  All or nothing, decided on
+    // the WHOLE problem (every rank of a sharded run must assemble a system of the same order).
+    jaicov_problem_desc Dsyn;
+    std::vector<int32_t> syn_begin;
+    std::vector<int64_t> syn_off;
+    e->h_caller_block.clear();
+    {
+        const char *env = getenv("JAICOV_SCHUR");
+        bool ok = !(env && env[0] == '0') && e->opts.ordinary_group_elimination >= 0 && e->opts.assembly_mode == 0 && D->n_images > 0;
+        const int e0 = D->n_images > 0 ? D->eo_col[0] : -1;
+        ok = ok && e0 >= d && e0 + 6 * D->n_images == U;
+        for (int i = 0; ok && i < 6 * D->n_images; i++) ok = D->eo_col[i] == e0 + i;
+        const int s_eo = 3 * D->n_points + 3 * D->n_cameras + D->n_dist;
+        for (int r = 0; ok && r < D->n_direct_rows; r++) ok = D->dg_slot[r] < s_eo;
+        std::vector<int32_t> img_b(D->n_images + 1, 0), img_blk(std::max(1, D->n_images), -1);
+        if (ok) {
+            for (int ip = 0; ip < D->n_image_points; ip++) {
+                if (D->ip_image[ip] < 0 || D->ip_image[ip] >= D->n_images) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "image index out of range");
+                img_b[D->ip_image[ip] + 1]++;
+            }
+            for (int i = 0; i < D->n_images; i++) img_b[i + 1] += img_b[i];
+            for (int g = 0; ok && g < D->n_image_blocks; g++) {       // a caller's block must be ALL observations of its image
+                const int b = D->blk_ip_begin[g], en = D->blk_ip_begin[g + 1];
+                if (en <= b || b < 0 || en > D->n_image_points) { ok = false; break; }
+                const int img = D->ip_image[b];
+                ok = img_b[img] == b && img_b[img + 1] == en && img_blk[img] < 0;
+                if (ok) img_blk[img] = g;
+            }
+            int64_t syn_bytes = 0;
+            bool any = false;
+            for (int i = 0; ok && i < D->n_images; i++) {
+                const int64_t cnt = img_b[i + 1] - img_b[i];
+                if (img_blk[i] >= 0) continue;
+                any = true;
+                ok = cnt >= 3 && 2 * cnt <= 4096;
+                syn_bytes += 4 * cnt * cnt * (int64_t)sizeof(double);
+            }
+            ok = ok && any && syn_bytes <= ((int64_t)16 << 30);
+        }
+        if (ok) {
+            syn_begin.push_back(0);
+            for (int i = 0; i < D->n_images; i++) {
+                syn_begin.push_back(img_b[i + 1]);
+                syn_off.push_back(img_blk[i] >= 0 ? D->blk_disp_offset[img_blk[i]] : (int64_t)-1);
+                e->h_caller_block.push_back(img_blk[i]);
+            }
+            Dsyn = *D;
+            Dsyn.n_image_blocks = D->n_images;
+            Dsyn.blk_ip_begin = syn_begin.data();
+            Dsyn.blk_disp_offset = syn_off.data();
+            D = &Dsyn;
+            e->synthesized_blocks = true;
+        }
     }
     // ---- blocks / segments -------------------------------------------------------------------------------------
     std::vector<uint8_t> in_block(D->n_image_points + 1, 0);
@@ -669,33 +835,30 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
         if ((rc = dalloc(e, (size_t)dg_total, &d_dgw))) return rc;
         p.dg_w = d_dgw;
         if ((rc = upload(e, dg_w_off.data(), (size_t)D->n_direct_groups, &p.dg_w_offset))) return rc;
-        const int mmax = std::max(e->max_m, max_dm);
-        if (mmax > 0) {
-            DenseSolver ds;
-            const int mp = ((mmax + 127) / 128) * 128;
-            HIPE(e, ds.init(e->stream, mp, true));
-            double *d_tmp = nullptr;
+        {
+            std::vector<DispItem> items;
             const int32_t *d_perm_local = nullptr;
-            if (!perm_local.empty() && (rc = upload(e, perm_local.data(), perm_local.size(), &d_perm_local))) { ds.release(); return rc; }
-            hipError_t he = hipMalloc(&d_tmp, (size_t)mmax * mmax * sizeof(double));
-            if (he != hipSuccess) { ds.release(); HIPE(e, he); }
-            int status = JAICOV_OK;
-            for (size_t t = 0; t < blk_list.size() && status == JAICOV_OK; t++) {
-                const int g = blk_list[t];
+            if (!perm_local.empty() && (rc = upload(e, perm_local.data(), perm_local.size(), &d_perm_local))) return rc;
+            for (int g : blk_list) {
                 const int m = 2 * (D->blk_ip_begin[g + 1] - D->blk_ip_begin[g]);
-                hipMemcpyAsync(d_tmp, D->blk_disp + D->blk_disp_offset[g], (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, e->stream);
-                status = invert_dispersion(e, ds, d_tmp, m, d_w + blk_w_off[g], d_perm_local ? d_perm_local + D->blk_ip_begin[g] : nullptr);
+                if (D->blk_disp_offset[g] < 0) {      // an ordinary image: inv(D) = diag of 2 x 2 blocks in closed form, engine order (PDF:296-319)
+                    hipLaunchKernelGGL(fill_diag_weight_kernel, dim3(m), dim3(256), 0, e->stream, p.ip_var_x, p.ip_var_y, p.ip_rho,
+                                       D->blk_ip_begin[g], m, d_w + blk_w_off[g]);
+                    continue;
+                }
+                items.push_back(DispItem{D->blk_disp + D->blk_disp_offset[g], d_w + blk_w_off[g], d_perm_local ? d_perm_local + D->blk_ip_begin[g] : nullptr, m});
             }
-            for (int g = 0; g < D->n_direct_groups && status == JAICOV_OK; g++) {
+            for (int g = 0; g < D->n_direct_groups; g++) {
                 if (dg_w_off[g] < 0) continue;
-                const int m = D->dg_row_begin[g + 1] - D->dg_row_begin[g];
-                hipMemcpyAsync(d_tmp, D->dg_disp + D->dg_disp_offset[g], (size_t)m * m * sizeof(double), hipMemcpyHostToDevice, e->stream);
-                status = invert_dispersion(e, ds, d_tmp, m, d_dgw + dg_w_off[g]);
+                items.push_back(DispItem{D->dg_disp + D->dg_disp_offset[g], d_dgw + dg_w_off[g], nullptr, D->dg_row_begin[g + 1] - D->dg_row_begin[g]});
             }
-            hipStreamSynchronize(e->stream);
-            hipFree(d_tmp);
-            ds.release();
-            if (status != JAICOV_OK) return status;
+            (void)max_dm;
+            e->h_perm_local = perm_local;
+            e->h_blk_w_off.assign(blk_w_off.begin(), blk_w_off.end());
+            e->h_blk_ip_begin.assign(D->blk_ip_begin, D->blk_ip_begin + D->n_image_blocks + 1);
+            e->h_blk_mine.assign(D->n_image_blocks, 0);
+            for (int g : blk_list) e->h_blk_mine[g] = 1;
+            if ((rc = invert_dispersions(e, items))) return rc;
         }
     }
 
@@ -793,7 +956,10 @@ extern "C" int jaicov_neq_create(const jaicov_problem_desc *desc, const jaicov_e
         e->opts.apply_shared = 1;
     }
     *out = e;     // returned even on failure so that the caller can read jaicov_neq_last_error(); destroy() frees it
-    return create_impl(e, desc, opts);
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = create_impl(e, desc, opts);
+    e->create_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
 }
 
 extern "C" size_t jaicov_neq_num_slots(const jaicov_engine *e) { return e ? (size_t)e->n_slots : 0; }
@@ -1161,6 +1327,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     bool fast_refined = false;
     int info = 0;
     for (int attempt = 0;; attempt++) {
+    HIPE(e, slv.begin_refactor());      // the side stream's premultiply of the last pass may still read the old factor: nothing writes L before this
     if (!fused)
         hipLaunchKernelGGL(scale_copy_kernel, dim3((c1 + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
                            Up, d, e->d_V, e->d_B, Upad, 0, c1);
@@ -1600,6 +1767,39 @@ extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t 
     }
     if (n >= 11) stats[10] = e->last_refine_correction;
     if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = e->dm_stat_passes = e->dm_stat_ms = e->dm_stat_flops = 0.0;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_create_timings(jaicov_engine *e, double *ms, int32_t n) {
+    if (!e || !ms) return JAICOV_ERR_BAD_ARGUMENT;
+    for (int i = 0; i < n && i < 4; i++) ms[i] = e->create_ms[i];
+    return JAICOV_OK;
+}
+
+// diagnostic / parity hook: the cached inverse dispersion inv(D) of image block `block` (DOPG:82-86 caches sigma0^2 inv(D / sigma0^2),
+// which is sigma0^2 times this), m x m row-major in the CALLER's order of the block's observations
+extern "C" int jaicov_neq_get_block_weight(jaicov_engine *e, int32_t block, double *out, size_t len) {
+    if (!e || !out) return JAICOV_ERR_BAD_ARGUMENT;
+    if (!e->h_caller_block.empty()) {      // the engine's internal blocks are the images; find the caller's
+        int internal = -1;
+        for (size_t g = 0; g < e->h_caller_block.size(); g++)
+            if (e->h_caller_block[g] == block) internal = (int)g;
+        block = internal;
+    }
+    if (block < 0 || block >= (int)e->h_blk_mine.size() || !e->h_blk_mine[block]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "no such image block on this engine");
+    const int b = e->h_blk_ip_begin[block], mpts = e->h_blk_ip_begin[block + 1] - b, m = 2 * mpts;
+    if (len != (size_t)m * m) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "len must be (2 * points of the block)^2");
+    HIPE(e, hipSetDevice(e->device));
+    std::vector<double> w((size_t)m * m);
+    HIPE(e, hipMemcpy(w.data(), e->p.blk_w + e->h_blk_w_off[block], w.size() * sizeof(double), hipMemcpyDeviceToHost));
+    const int32_t *perm = e->h_perm_local.empty() ? nullptr : e->h_perm_local.data() + b;
+    for (int i = 0; i < m; i++) {
+        const int si = perm ? 2 * perm[i >> 1] + (i & 1) : i;
+        for (int j = 0; j < m; j++) {
+            const int sj = perm ? 2 * perm[j >> 1] + (j & 1) : j;
+            out[(size_t)si * m + sj] = w[(size_t)i * m + j];
+        }
+    }
     return JAICOV_OK;
 }
 

@@ -28,6 +28,7 @@ EXPORTS = [
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_dispersion_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
     "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats", "jaicov_neq_cancel",
     "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm", "jaicov_neq_eo_step_buffer",
+    "jaicov_neq_create_timings", "jaicov_neq_get_block_weight",
 ]
 
 KROW = 32  # 12 + JAICOV_MAX_DIST_PER_CAMERA
@@ -48,7 +49,8 @@ class EngineOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("image_begin", C.c_int32),
                 ("image_end", C.c_int32), ("apply_shared", C.c_int32), ("assembly_mode", C.c_int32),
                 ("block_size", C.c_int32), ("reduced_reference_quirk", C.c_int32), ("deterministic", C.c_int32), ("refinement", C.c_int32),
-                ("reserved", C.c_int32 * 5)]
+                ("ordinary_group_elimination", C.c_int32), ("dispersion_refinement", C.c_int32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class EstimateOptions(C.Structure):
@@ -115,6 +117,8 @@ def load_library():
     L.jaicov_neq_set_profiling.argtypes = [vp, C.c_int]
     L.jaicov_neq_kernel_stats.argtypes = [vp, _pd, C.c_int32, C.c_int]
     L.jaicov_neq_cancel.argtypes = [vp]
+    L.jaicov_neq_create_timings.argtypes = [vp, _pd, C.c_int32]
+    L.jaicov_neq_get_block_weight.argtypes = [vp, C.c_int32, _pd, C.c_size_t]
     L.jaicov_dense_spd_solve_packed.argtypes = [C.c_int32, _pd, _pd, C.c_int32, C.c_int32, _pd]
     L.jaicov_dense_gemm.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, _pd, C.c_int64,
                                     _pd, C.c_int64, C.c_double, _pd, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _pd]
@@ -130,7 +134,8 @@ class Engine:
     """One engine per adjustment (``BundleAdjustment`` is single-shot: BundleAdjustment.java:203)."""
 
     def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0,
-                 reduced_reference_quirk: bool = False, deterministic: bool = False, refinement: int = 0):
+                 reduced_reference_quirk: bool = False, deterministic: bool = False, refinement: int = 0,
+                 ordinary_group_elimination: int = 0, dispersion_refinement: int = 0):
         self.L = load_library()
         self.fp = fp
         self.U = fp.n_unknowns
@@ -143,6 +148,8 @@ class Engine:
         opts.assembly_mode = int(assembly_mode)
         opts.reduced_reference_quirk = int(reduced_reference_quirk)
         opts.deterministic = int(deterministic)
+        opts.ordinary_group_elimination = int(ordinary_group_elimination)   # < 0: ordinary image groups stay outside the EO pre-elimination
+        opts.dispersion_refinement = int(dispersion_refinement)             # < 0: inv(D) as the blocked Cholesky leaves it
         opts.refinement = int(refinement)      # 0 = default (one step of iterative refinement per solve), < 0 = none, k = k steps
         self._h = C.c_void_p()
         rc = self.L.jaicov_neq_create(C.byref(self._desc), C.byref(opts), C.byref(self._h))
@@ -271,6 +278,19 @@ class Engine:
         ms = np.zeros(8)
         self._chk(self.L.jaicov_neq_last_timings(self._h, _p(ms), 8))
         return dict(zip(("rows", "assembly", "finalize", "factor", "solve", "inverse", "omega", "total"), ms))
+
+    def create_timings(self):
+        """What jaicov_neq_create spent, ms of host wall clock."""
+        ms = np.zeros(4)
+        self._chk(self.L.jaicov_neq_create_timings(self._h, _p(ms), 4))
+        return {"create_ms": float(ms[0]), "dispersion_upload_host_ms": float(ms[1]), "dispersions_to_weights_ms": float(ms[2])}
+
+    def get_block_weight(self, block):
+        """inv(D) of image block `block` as cached at create (DOPG:82-86 caches sigma0^2 times it), caller's observation order."""
+        m = 2 * int(self.fp.blk_ip_begin[block + 1] - self.fp.blk_ip_begin[block])
+        out = np.zeros((m, m))
+        self._chk(self.L.jaicov_neq_get_block_weight(self._h, int(block), _p(out), out.size))
+        return out
 
     def set_profiling(self, on=True):
         self._chk(self.L.jaicov_neq_set_profiling(self._h, int(on)))

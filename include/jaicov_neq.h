@@ -169,7 +169,19 @@ typedef struct jaicov_engine_options {
                                       and one backward substitution, csrc/refine.hip): the error of dx against the exact solution of the
                                       assembled system falls from cond * eps (2.6e-8 at config 4, where the reference's dspsv, MX:338-353, is
                                       at 3.6e-9) to ~1e-12.  Costs ~1 ms per pass at config 4.  JAICOV_REFINE=k overrides.                  */
-    int32_t  reserved[5];
+    int32_t  ordinary_group_elimination; /* 0 = default: when the whole problem qualifies (every image has >= 3 observations, at most 2048 per
+                                      image without a dispersion of its own, the exterior orientations own the trailing columns and are
+                                      not directly observed) the exterior orientations of images whose points are ORDINARY ImageCoordinate
+                                      groups (diagonal / 2 x 2 weights) are pre-eliminated on the device like those of jointly dispersed
+                                      images -- reduceNormalEquationSystem, BA:1197-1342, serves every image --: such an image is held as an
+                                      image block with a block-diagonal inv(D) (8 (2 n)^2 bytes for n observations).  < 0: off, ordinary
+                                      groups are assembled one by one into the full-order system (the path of rounds 1-3).               */
+    int32_t  dispersion_refinement; /* 0 = default: every inverse dispersion (DOPG:82-86) gets one Newton-Schulz step X <- X + X (I - D X) at
+                                      create, with the residual formed by error-free splitting on the fp64 matrix cores (batchinv.hip): the
+                                      forward error of inv(D) falls from cond(D) * eps (3e-11 at config 4, the reference's dpptrf + dpptri the
+                                      same) to ~1e-14, and with it the error of N = A' inv(D) A against the exactly assembled system.  Four
+                                      more GEMMs per matrix (+80 ms of engine creation at config 4).  < 0: off.                              */
+    int32_t  reserved[3];
 } jaicov_engine_options;
 
 typedef struct jaicov_engine jaicov_engine;
@@ -321,6 +333,13 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
  * the slow-path poll also finds flags that were simply set late); bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
  * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).                                     */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
+/* What jaicov_neq_create spent (ms, wall clock of the host): [0] the whole call, [1] host time inside the uploads of the dense
+ * dispersions (pageable host memory -> device), [2] dispersions -> weights altogether (upload + batched inversion, DOPG:82-86).   */
+int jaicov_neq_create_timings(jaicov_engine *e, double *ms, int32_t n);
+/* Parity hook for DOPG:82-86 / MX:304-324: inv(D) of image block `block` as the engine caches it (the reference caches
+ * sigma0^2 times it), row-major m x m with m = 2 * (points of the block), rows and columns in the caller's observation order;
+ * len must be m * m.                                                                                                            */
+int jaicov_neq_get_block_weight(jaicov_engine *e, int32_t block, double *out, size_t len);
 int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset);
 
 #ifdef __cplusplus

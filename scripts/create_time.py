@@ -1,9 +1,11 @@
-import sys, time
-sys.path.insert(0, "/root/repo")
+"""Engine creation at config 4 (4 GB of dense dispersions -> weights) and the whole adjustment behind it."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bundle_adjustment_amd import engine, scene
-fp = scene.config("cfg4")
-for i in range(2):
+fp = scene.config(sys.argv[1] if len(sys.argv) > 1 else "cfg4")
+for i in range(3):
     t = time.perf_counter(); eng = engine.Engine(fp); t1 = time.perf_counter() - t
+    ct = eng.create_timings()
     t = time.perf_counter(); v, r = eng.estimate(invert=engine.INVERT_FULL); t2 = time.perf_counter() - t
-    print(f"create {t1:.3f} s, estimate to termination (FULL) {t2:.3f} s, iterations {r.iterations}, seconds_total {r.seconds_total:.3f}", flush=True)
+    print(f"create {t1:.3f} s {ct}, estimate to termination (FULL) {t2:.3f} s, iterations {r.iterations}, seconds_total {r.seconds_total:.3f}", flush=True)
     eng.close()

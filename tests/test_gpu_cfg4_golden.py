@@ -115,7 +115,11 @@ def test_pass1_dense_contraction_mode(cfg4_scene, gold):
 #   device solver alone, against the exact inverse of its own system:  REDUCED 4.5e-9, FULL (order 18 014 Cholesky)    2.4e-7
 #   the reference's dsptri against the exact inverse of ITS system                                                    2.7e-9
 # FULL_EXPANDED (what estimate() / estimateModel() run for MatrixInversion.FULL) builds all of Qxx from the REDUCED inverse.
-QTOL = {"FULL": 1.5e-6, "FULL_EXPANDED": 4e-7, "REDUCED": 4e-7}       # <= 3.3 x the floor for the product modes
+# Round 4 (tests/golden/cfg4/cfg4_exactN_pass2.*, make_exactN.py): the "floor" is the ORACLE's error.  Against the exact inverse of the
+# exactly assembled system: oracle (dpptrf + dpptri weights, dspsv + dsptri) 1.7e-7; device FULL_EXPANDED / REDUCED ~2e-8; literal FULL
+# (order 18 014 Cholesky) ~2.4e-7.  The device's weights and N are exact to fp64 rounding since the refinement of inv(D) at create.
+QTOL = {"FULL": 1.5e-6, "FULL_EXPANDED": 3e-7, "REDUCED": 3e-7}       # against the oracle: its own 1.7e-7 + the device's
+TTOL = {"FULL": 1e-6, "FULL_EXPANDED": 5e-8, "REDUCED": 5e-8}         # against the truth
 
 
 @pytest.mark.parametrize("mode", ["FULL", "FULL_EXPANDED", "REDUCED"])
@@ -149,6 +153,18 @@ def test_final_pass_step_omega_and_cofactors(cfg4_scene, gold, eng, mode):
     dq = float(np.abs(dg / z["diagQ"][:k] - 1.0).max())
     assert dq < QTOL[mode]                                            # achieved 4.1e-7 / 1.4e-7 / 1.5e-7, every one of the variances
     print(f"cfg4 final pass {mode}: dx {rel(dx2, z['dx2']):.2e}, Qxx sample {cs:.2e}, diag {dq:.2e}")
+    tp = os.path.join(G, "cfg4_exactN_pass2.npz")
+    if os.path.exists(tp):
+        t = np.load(tp)
+        tr = t["Qsample_true"][np.ix_(keep, keep)]
+        sdt = np.sqrt(np.abs(np.diag(tr)))
+        dev_t = float(np.abs((Qs - tr) / np.outer(sdt, sdt)).max())
+        orc_t = float(np.abs((ref - tr) / np.outer(sdt, sdt)).max())
+        print(f"   against the exact inverse of the exactly assembled system: device {dev_t:.2e}, oracle {orc_t:.2e}")
+        assert dev_t < TTOL[mode]                                     # achieved 2e-8 (product modes)
+        if mode != "FULL":
+            assert dev_t <= orc_t and cs <= orc_t + TTOL[mode]        # the device is closer to the truth than the reference algorithm
+        assert rel(dx2, t["dx_true"]) < 1e-9                          # the refined step against the EXACT step: achieved ~1e-11 (was: 1.8e-8 "floor")
     if mode != "REDUCED":
         fro = float(np.sqrt(2.0 * np.dot(Q, Q) - np.dot(dg, dg)))
         assert abs(fro - meta["qxx_frobenius"]) < QTOL[mode] * meta["qxx_frobenius"]     # achieved 1.1e-7

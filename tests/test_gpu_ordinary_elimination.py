@@ -1,0 +1,155 @@
+"""EO pre-elimination of images whose points are ORDINARY ImageCoordinate groups (diagonal / 2 x 2 weights), and the batched
+inversion of the dense dispersions at engine creation (round 4).
+
+reduceNormalEquationSystem (BundleAdjustment.java:1197-1342) eliminates the exterior orientation of every image; all three reference
+examples run MatrixInversion.REDUCED (ExampleReport.java:89).  Through round 3 the device path of that elimination existed only for
+images with a joint dispersion; an ordinary image is now served as an image block with a block-diagonal weight (engine option
+ordinary_group_elimination, default on).  Everything is held to the oracle's full bordered solve (dspsv + dsptri at order U).
+"""
+import numpy as np
+import pytest
+
+from bundle_adjustment_amd import engine, scene
+from bundle_adjustment_amd.problem import packed_to_full
+
+pytestmark = pytest.mark.gpu
+
+
+SCENES = {
+    "tiny": lambda: scene.config("tiny"),                # 2 x 2 weights, control points
+    "tiny_free": lambda: scene.config("tiny_free"),      # diagonal weights, free network (d = 6), scale bar
+    "cfg2": lambda: scene.config("cfg2"),                # BASELINE config 2: 20 x 200, diagonal weights
+}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+@pytest.mark.parametrize("lam", [0.0, 0.5])
+def test_ordinary_images_are_pre_eliminated(oracle_mod, name, lam):
+    fp = SCENES[name]()
+    U, s2 = fp.n_unknowns, fp.sigma2apriori
+    assert fp.n_image_blocks == 0
+    o = oracle_mod.Oracle(fp)
+    dxo, _, No, no = o.step(fp.values, s2, lam, False)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.build(s2, lam)
+    assert eng.reduced_order() == U - 6 * fp.n_images                     # the EO columns are gone from the system
+    dx = eng.solve(False)
+    np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    om_o = o.omega(fp.values, s2, dxo)
+    assert abs(eng.omega(s2, dx) - om_o) <= 1e-9 * om_o
+    # the unreduced system, as the reference stacks it (PDF:475-505), through the same block kernels
+    eng.prepare_inverse(engine.INVERT_FULL)
+    eng.build(s2, lam)
+    assert eng.reduced_order() == U
+    N, n = eng.get_normal()
+    Nref, nref, _ = o.build(fp.values, s2, lam)
+    d = fp.rank_defect
+    Nf, Rf = packed_to_full(N, U), packed_to_full(Nref, U)
+    np.testing.assert_allclose(Nf[d:, d:], Rf[d:, d:], rtol=0, atol=1e-11 * np.abs(Rf).max())
+    np.testing.assert_allclose(n, nref, rtol=0, atol=1e-11 * np.abs(nref).max())
+    eng.close()
+    # the old path (ordinary groups one by one into the full-order system) stays available and agrees
+    old = engine.Engine(fp, ordinary_group_elimination=-1)
+    old.set_parameters(fp.values)
+    old.build(s2, lam)
+    assert old.reduced_order() == U
+    np.testing.assert_allclose(old.solve(False), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    old.close()
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_free"])
+def test_reduced_inverse_of_ordinary_images_is_the_block_of_the_full_cofactor(oracle_mod, name):
+    """MatrixInversion.REDUCED (BA:261-267) and FULL (expanded from the reduced inverse) on ordinary image groups against the
+    oracle's dspsv + dsptri of the full bordered system."""
+    fp = SCENES[name]()
+    U, s2 = fp.n_unknowns, fp.sigma2apriori
+    o = oracle_mod.Oracle(fp)
+    dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, True)
+    Qo = packed_to_full(Qo, U)
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    for inv in (engine.INVERT_REDUCED, engine.INVERT_FULL_EXPANDED):
+        eng.prepare_inverse(inv)
+        eng.build(s2, 0.0)
+        dx = eng.solve(inv)
+        np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+        k = eng.cofactor_order()
+        assert k == (U - 6 * fp.n_images if inv == engine.INVERT_REDUCED else U)
+        Q = packed_to_full(eng.get_cofactor(), k)
+        np.testing.assert_allclose(Q, Qo[:k, :k], rtol=0, atol=1e-8 * np.abs(Qo).max())
+    eng.close()
+
+
+def test_estimate_on_ordinary_images_matches_oracle(oracle_mod):
+    """The whole loop (jaicov_neq_estimate, MatrixInversion.REDUCED) on BASELINE config 2 with the elimination on and off."""
+    fp = scene.config("cfg2")
+    vo, Qo, ro = oracle_mod.Oracle(fp).estimate()
+    for flag in (0, -1):
+        eng = engine.Engine(fp, ordinary_group_elimination=flag)
+        v, r = eng.estimate(invert=engine.INVERT_REDUCED)
+        assert r.state == 1 and r.iterations == ro.iterations
+        assert np.abs(v - vo).max() <= 1e-9 * 2000.0
+        assert abs(r.omega - ro.omega) <= 1e-9 * ro.omega
+        k, kr = eng.cofactor_order(), fp.n_unknowns - 6 * fp.n_images
+        assert k == (kr if flag == 0 else fp.n_unknowns)                 # without the elimination REDUCED is served by the full inverse (jaicov_neq.h)
+        assert eng.reduced_order() == k
+        Q = packed_to_full(eng.get_cofactor(), k)[:kr, :kr]
+        Qr = packed_to_full(Qo, fp.n_unknowns)[:kr, :kr]
+        assert np.abs(Q - Qr).max() <= 2e-9 * np.abs(Qr).max()
+        eng.close()
+
+
+def test_problems_that_do_not_qualify_keep_the_full_order_path(oracle_mod):
+    """A disqualifier -- here: a joint dispersion that covers only PART of its image's observations, so that the image's exterior
+    orientation is shared by two observation groups -- leaves ALL ordinary groups outside the elimination: the decision is
+    all-or-nothing over the whole problem (every rank of a sharded run must assemble a system of the same order)."""
+    import dataclasses
+    fp = scene.config("tiny_block")
+    m0 = 2 * int(fp.blk_ip_begin[1] - fp.blk_ip_begin[0])
+    D0 = fp.blk_disp[:m0 * m0].reshape(m0, m0)[4:, 4:]                   # the first two points of image 0 leave the block ...
+    begin = fp.blk_ip_begin.copy(); begin[0] += 2
+    off = fp.blk_disp_offset.copy(); off[1:] -= m0 * m0 - D0.size
+    disp = np.concatenate([D0.ravel(), fp.blk_disp[m0 * m0:]])
+    var_x, var_y = fp.ip_var_x.copy(), fp.ip_var_y.copy()                 # ... and are ordinary groups with their own variances
+    fp2 = dataclasses.replace(fp, blk_ip_begin=begin, blk_disp_offset=off, blk_disp=disp, ip_var_x=var_x, ip_var_y=var_y,
+                              n_observations=0).validate()
+    o = oracle_mod.Oracle(fp2)
+    s2 = fp2.sigma2apriori
+    dxo, _, _, _ = o.step(fp2.values, s2, 0.0, False)
+    eng = engine.Engine(fp2)
+    eng.set_parameters(fp2.values)
+    eng.build(s2, 0.0)
+    assert eng.reduced_order() == fp2.n_unknowns
+    np.testing.assert_allclose(eng.solve(False), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    eng.close()
+
+
+@pytest.mark.parametrize("m_points", [8, 64, 70, 200, 330])
+def test_batched_dispersion_inverse_matches_the_references_dpptri(oracle_mod, m_points):
+    """DOPG:82-86 at engine creation: all dispersions of one padded order are inverted in one set of batched launches (batchinv.hip).
+    jaicov_neq_get_block_weight returns inv(D) in the CALLER's observation order (the engine keeps blocks column-sorted);
+    oracle_dispersion_to_weight = dpptrf + dpptri of D / sigma0^2.  Orders 4 .. 570: one to five diagonal blocks (ragged last level of the triangular inverse), two padded orders in one problem."""
+    fp = scene.make_scene(6, int(m_points / 0.55) + 12, m_points, dist=scene.DIST_RADIAL, weights="block", n_control=4, control_dense=True)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    eng = engine.Engine(fp)
+    for b in range(fp.n_image_blocks):
+        W = eng.get_block_weight(b) * s2
+        ref = o.block_weight(s2, b)
+        assert np.abs(W - ref).max() <= 1e-9 * np.abs(ref).max()
+        assert np.abs(W - W.T).max() == 0.0
+    ct = eng.create_timings()
+    assert ct["create_ms"] > 0 and ct["dispersions_to_weights_ms"] > 0
+    eng.close()
+
+
+def test_not_positive_definite_dispersion_is_reported():
+    fp = scene.make_scene(4, 40, 20, dist=scene.DIST_RADIAL, weights="block", n_control=4)
+    m = 2 * int(fp.blk_ip_begin[2] - fp.blk_ip_begin[1])
+    off = int(fp.blk_disp_offset[1])
+    D = fp.blk_disp[off:off + m * m].reshape(m, m)
+    D[3, 3] = -D[3, 3]
+    with pytest.raises(engine.EngineError) as ei:
+        engine.Engine(fp)
+    assert ei.value.code == 1                                             # JAICOV_ERR_SINGULAR: MatrixNotSPDException (DOPG:85-86)

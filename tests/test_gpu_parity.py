@@ -594,15 +594,21 @@ def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     dxo, _, _, _ = o.step(fp.values, s2, 0.0, False)
     eng = engine.Engine(fp)
     eng.set_parameters(fp.values)
+    eng.prepare_inverse(engine.INVERT_FULL)        # the unreduced N, as the reference stacks it (round 4: the default build pre-eliminates the EO of ordinary images too)
     eng.build(s2, 0.0)
+    assert eng.reduced_order() == U
     N, n = eng.get_normal()
     dgo = np.sqrt(np.abs(No[np.arange(U) * (np.arange(U) + 3) // 2])); dgo[dgo == 0] = 1.0
     r, c = np.triu_indices(U)                      # packed 'U' is column-major upper: index r + c(c+1)/2
     rel = np.abs(N - No) / (dgo[r[np.argsort(r + c * (c + 1) // 2)]] * dgo[c[np.argsort(r + c * (c + 1) // 2)]])
     assert rel.max() < 1e-11
     np.testing.assert_allclose(n, no, rtol=0, atol=1e-11 * np.abs(no).max())
-    dx = eng.solve(False)
+    dx = eng.solve(False)                          # order 3 614: 29 block columns
     np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
+    eng.prepare_inverse(engine.INVERT_NONE)        # the product path: order 3 014 after the elimination, 24 block columns
+    eng.build(s2, 0.0)
+    assert eng.reduced_order() == U - 6 * fp.n_images
+    np.testing.assert_allclose(eng.solve(False), dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
     eng.close()
 
 

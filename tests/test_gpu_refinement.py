@@ -153,11 +153,11 @@ def test_full_cofactor_expanded_from_the_reduced_inverse(oracle_mod, free_networ
 
 
 def test_expanded_mode_falls_back_to_full_where_it_cannot_apply(oracle_mod):
-    """No dense image blocks -> no EO pre-elimination: FULL_EXPANDED is served as FULL (like REDUCED is, jaicov_neq.h)."""
+    """No EO pre-elimination (here: ordinary image groups kept outside it) -> FULL_EXPANDED is served as FULL (like REDUCED is, jaicov_neq.h)."""
     fp = scene.config("tiny")
     o = oracle_mod.Oracle(fp)
     dxo, Qo, _, _ = o.step(fp.values, fp.sigma2apriori, 0.0, True)
-    eng = engine.Engine(fp)
+    eng = engine.Engine(fp, ordinary_group_elimination=-1)
     eng.set_parameters(fp.values)
     eng.prepare_inverse(engine.INVERT_FULL_EXPANDED)
     eng.build(fp.sigma2apriori, 0.0)

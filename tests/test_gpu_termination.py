@@ -40,7 +40,16 @@ def relative_parameter_error(fp, got, ref):
     return float((np.abs(got - ref) / den).max())
 
 
-def run_to_termination(fp, z, meta, invert, deterministic, qtol, check_values=1e-9):
+def truth(cfg):
+    """tests/golden/<cfg>/<cfg>_exactN.*: the normal equations of the converged point assembled in extended precision and inverted
+    exactly (make_exactN.py) -- and what the ORACLE's dspsv + dsptri result is worth against it (round 4)."""
+    p = os.path.join(G, cfg, f"{cfg}_exactN")
+    if not os.path.exists(p + ".npz"):
+        pytest.skip(f"{p}.npz not generated")
+    return dict(np.load(p + ".npz")), json.load(open(p + ".json"))
+
+
+def run_to_termination(fp, z, meta, invert, deterministic, qtol, check_values=1e-9, exact=None, ttol=None):
     eng = engine.Engine(fp, deterministic=deterministic)
     values, res = eng.estimate(invert=invert)
     try:
@@ -62,6 +71,20 @@ def run_to_termination(fp, z, meta, invert, deterministic, qtol, check_values=1e
         sd = np.sqrt(np.abs(np.diag(ref)))
         cq = float((np.abs(Qs - ref) / np.outer(sd, sd)).max())
         assert dq < qtol and cq < qtol, (dq, cq)
+        if exact is not None:
+            # WHOSE error is the difference to the oracle?  Against the exact inverse of the exactly assembled system the device
+            # must be (i) within ttol, (ii) no further away than the reference algorithm is, and (iii) its distance to the oracle
+            # must be explained by the oracle's own error (triangle inequality)
+            t, tm = exact
+            assert np.array_equal(t["sample_cols"], cols)
+            tr = t["Qsample_true"][np.ix_(keep, keep)]
+            sdt = np.sqrt(np.abs(np.diag(tr)))
+            dev_t = float((np.abs(Qs - tr) / np.outer(sdt, sdt)).max())
+            orc_t = float((np.abs(ref - tr) / np.outer(sdt, sdt)).max())
+            assert dev_t < ttol, dev_t
+            assert dev_t <= orc_t, (dev_t, orc_t)
+            assert cq <= orc_t + ttol, (cq, orc_t)
+            print(f"   against the exact inverse: device {dev_t:.2e}, oracle (reference algorithm) {orc_t:.2e}, device vs oracle {cq:.2e}")
         return err, dq, cq, res
     finally:
         eng.close()
@@ -86,7 +109,9 @@ def test_config3_with_dense_dispersions_runs_to_the_references_termination(inver
     a 15-minute fixture (tests/golden/make_cfg3b_golden.py)."""
     z, meta = load("cfg3b")
     fp = scene.config("cfg3_block")
-    err, dq, cq, res = run_to_termination(fp, z, meta, invert, deterministic, qtol=5e-8)
+    # Qxx against the oracle's dsptri: achieved 9e-9 .. 1.0e-8, of which 8.6e-9 .. 9.8e-9 are the ORACLE's distance from the exact
+    # inverse (cfg3b_exactN.json); the device's own distance: 5e-10 .. 7e-10 (asserted < 2e-9)
+    err, dq, cq, res = run_to_termination(fp, z, meta, invert, deterministic, qtol=2e-8, exact=truth("cfg3b"), ttol=2e-9)
     print(f"cfg3b invert={invert} det={deterministic}: iterations {res.iterations}, max|dx| {res.max_abs_dx:.2e}, parameters {err:.2e}, "
           f"diag Qxx {dq:.2e}, sample {cq:.2e}")
 
@@ -95,8 +120,10 @@ def test_config3_with_dense_dispersions_runs_to_the_references_termination(inver
 @pytest.mark.parametrize("invert", [engine.INVERT_FULL, engine.INVERT_REDUCED])
 def test_config4_runs_to_the_references_termination(cfg4_scene, invert, deterministic):
     z, meta = load("cfg4")
-    # Qxx at cond ~ 1e9: the floor set by the assembly's rounding is stated in DESIGN.md (profiles/r03_cfg4_accuracy.json)
-    err, dq, cq, res = run_to_termination(cfg4_scene, z, meta, invert, deterministic, qtol=4e-7)   # achieved 1.7e-7; floor 1.2e-7
+    # Qxx at cond ~ 1e9 against the oracle's dsptri: achieved 2.0e-7 .. 2.3e-7 -- the ORACLE's own distance from the exact inverse
+    # of the exactly assembled system is 2.1e-7 .. 2.3e-7 (cfg4_exactN.json: the reference's fp64 dpptrf + dpptri weights at
+    # cond(D) = 2e7); the device's distance from that truth: 1.7e-8 .. 2.2e-8 (asserted < 5e-8)
+    err, dq, cq, res = run_to_termination(cfg4_scene, z, meta, invert, deterministic, qtol=3e-7, exact=truth("cfg4"), ttol=5e-8)
     print(f"cfg4 invert={invert} det={deterministic}: iterations {res.iterations}, max|dx| {res.max_abs_dx:.2e}, parameters {err:.2e}, "
           f"diag Qxx {dq:.2e}, sample {cq:.2e}")
 
@@ -135,4 +162,4 @@ def test_host_estimate_model_runs_to_the_references_termination(cfg, request):
     sd = np.sqrt(np.abs(np.diag(ref)))
     cq = float((np.abs(Qs - ref) / np.outer(sd, sd)).max())
     print(f"{cfg} host estimateModel: iterations {ba.getIterations()}, parameters {err:.2e}, Qxx sample ({int(keep.sum())} point columns) {cq:.2e}")
-    assert cq < {"cfg3": 2e-8, "cfg3b": 5e-8, "cfg4": 4e-7}[cfg]
+    assert cq < {"cfg3": 2e-8, "cfg3b": 2e-8, "cfg4": 3e-7}[cfg]       # cfg3b / cfg4: the oracle's own error, see the tests above

@@ -280,3 +280,66 @@ def test_reduced_mode_leaves_the_unsolved_rhs_in_the_eo_step(oracle_mod):
     dx_full, _, _, _ = o.step(fp.values, s2)
     np.testing.assert_allclose(n[:k], dx_full[:k], rtol=0, atol=1e-9 * np.abs(dx_full[:k]).max())
     assert np.abs(n[k:] - dx_full[k:]).max() > 1e-3 * np.abs(dx_full[k:]).max()      # far from the solution away from convergence
+
+
+# ---- ground truth (oracle/ba_exact.c): NOT the reference's arithmetic, the yardstick for the accuracy study ---------------------
+def test_extended_precision_weight_is_certified_in_binary128(oracle_mod):
+    """sigma0^2 inv(D) in x87 extended precision + one compensated Newton step, against a binary128 residual: an ill-conditioned
+    dispersion (cond ~ 1e5; config 4's: 2e7) where the fp64 dpptrf + dpptri of the reference (DOPG:82-86) loses 5 digits."""
+    L = oracle_mod.lib()
+    fp = scene.make_scene(3, 300, 300, dist=scene.DIST_RADIAL, weights="block", n_control=4)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    Ph, Pl = o.exact_block_weight(s2, 0)
+    P64 = o.block_weight(s2, 0)
+    m = Ph.shape[0]
+    D = fp.blk_disp[fp.blk_disp_offset[0]:fp.blk_disp_offset[0] + m * m].copy()
+    cond = np.linalg.cond(D.reshape(m, m))
+    assert cond > 1e4
+    pd = oracle_mod._p
+    r_exact = L.oracle_inverse_residual_q(m, pd(D), pd(Ph), pd(Pl), s2, 0, 64)      # 64 rows: binary128 is software arithmetic
+    r_fp64 = L.oracle_inverse_residual_q(m, pd(D), pd(P64), None, s2, 0, 64)
+    assert r_exact < 1e-14 and r_exact < 1e-3 * r_fp64, (r_exact, r_fp64, cond)
+    # the fp64 inverse agrees with it to cond * eps, no better
+    err = np.abs(P64 - Ph).max() / np.abs(Ph).max()
+    assert 1e-16 < err < 1e-9, err
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
+def test_extended_precision_assembly_agrees_with_the_restatement(oracle_mod, name):
+    """oracle_exact_accumulate (every group kind: ordinary 2 x 2 / diagonal image points, dense image blocks, scale bar, dense and
+    diagonal directly observed groups) against oracle_accumulate on well-conditioned scenes: the same N and n to fp64 rounding; the
+    (hi, lo) pair carries the extra bits."""
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    N, n = o.accumulate(fp.values, s2)
+    Nh, Nl, nh, nl = o.exact_accumulate(fp.values, s2)
+    assert np.abs(N - Nh).max() <= 2e-14 * np.abs(Nh).max()
+    assert np.abs(n - nh).max() <= 2e-13 * np.abs(nh).max()
+    assert np.abs(Nl).max() <= 2.0 ** -52 * np.abs(Nh).max() and np.abs(Nl).max() > 0
+    # extended residual of the (hi, lo) system: r = b - (N_hi + N_lo) x
+    L = oracle_mod.lib()
+    U = fp.n_unknowns
+    x = np.random.default_rng(1).standard_normal(U)
+    y = np.zeros(U)
+    L.oracle_matvec_ld2(U, oracle_mod._p(Nh), oracle_mod._p(Nl), oracle_mod._p(x), oracle_mod._p(y))
+    full = packed_to_full(Nh, U) + packed_to_full(Nl, U)
+    np.testing.assert_allclose(y, full @ x, rtol=1e-12, atol=1e-12 * np.abs(y).max())
+
+
+def test_exact_fixtures_say_the_reference_algorithm_is_the_noisier_side():
+    """tests/golden/*/..._exactN.json (make_exactN.py): what the truth fixtures hold about the ORACLE (= the reference's dpptrf + dpptri
+    weights, fp64 stacking, dspsv + dsptri): its Qxx is 1e-8 (config 3 size) / 2.3e-7 (config 4) from the exact inverse of the exactly
+    assembled system -- the GPU tests hold the device against the same truth (test_gpu_termination.py, test_gpu_cfg4_golden.py)."""
+    import json
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for cfg, lo, hi in (("cfg3b", 2e-9, 5e-8), ("cfg4", 5e-8, 1e-6)):
+        meta = json.load(open(os.path.join(g, cfg, f"{cfg}_exactN.json")))
+        z = np.load(os.path.join(g, cfg, f"{cfg}_exactN.npz"))
+        assert lo < meta["oracle_Qsample_err"] < hi
+        assert meta["binary128_residual_exact_P"] < 1e-3 * meta["binary128_residual_oracle_P"]
+        assert meta["Qcols_last_correction"] < 2e-10          # the truth itself is converged to ~cond * 2^-64
+        Q = z["Qsample_true"]
+        assert np.abs(Q - Q.T).max() == 0 and np.all(np.diag(Q) > 0)
