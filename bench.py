@@ -166,7 +166,10 @@ def main():
 
     fp = scene.config(a.config)
     lo, hi = distributed.partition_images(fp, world)[rank]
-    eng = engine.Engine(fp, device=local, image_range=(lo, hi) if use_dist else None, apply_shared=(rank == 0))
+    t_create = time.perf_counter()
+    eng = engine.Engine(fp, device=local, image_range=(lo, hi) if use_dist else None, apply_shared=(rank == 0), expansion_exchange=use_dist)
+    create_wall_ms = 1e3 * (time.perf_counter() - t_create)
+    create_timings = eng.create_timings()
     eng.set_parameters(fp.values)
     s2 = fp.sigma2apriori
     if use_dist:
@@ -242,15 +245,21 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.config}: {fp.n_images} images x {fp.n_points} points, {fp.n_image_points} image points, "
                                    f"{fp.n_image_blocks} dense per-image dispersion blocks, U={U}, d={fp.rank_defect}",
-                       "parallelism": f"images sharded over {world} rank(s), packed N all-reduced, replicated solve",
+                       "parallelism": (f"images sharded over {world} rank(s), packed reduced N all-reduced (RCCL), solve REPLICATED on every rank: "
+                                       "expected_scaling predicts N > 1 slower than N = 1" if world > 1 or use_dist else
+                                       "1 rank: no collective; with N ranks the images shard, the packed reduced N is all-reduced and the solve is replicated"),
                        "rccl_ranks": (dist.get_world_size() if use_dist else 0)},
             "stage_ms_per_step": {k: v / a.steps for k, v in stage.items()},
             "flow": {"retries": flow[0], "stale_events": flow[1], "stale_confirmed": flow[2], "rescued": flow[3],
                      "ok": flow[0] == 0, "note": "summed over ranks since engine creation; retries > 0 = a factorisation was abandoned and repeated inside the timed region or the warm-up"},
-            "refinement": {"steps_per_solve": int(os.environ.get("JAICOV_REFINE", "1")), "last_correction_rel": ks["last_refinement_correction"],
+            # engine creation (one-time; jaicov_neq_create_timings): the FIRST engine of the process, which also pays the first launch of
+            # every kernel and the HIP context; scripts/create_time.py times the 2nd and 3rd (0.20 s at config 4)
+            "create_ms": {"wall_first_engine_of_the_process": create_wall_ms, **create_timings,
+                          "note": "dispersions_to_weights_ms = upload of the dense dispersions (dispersion_upload_host_ms of host time, pageable memory) + batched Cholesky / inverse / refinement (batchinv.hip)"},
+            "refinement": {"steps_per_solve": ks["refine_steps"], "last_correction_rel": ks["last_refinement_correction"],
                            "note": "iterative refinement of dx (two-fold-precision residual + forward/backward substitution), inside the timed step (stage 'solve')"},
             "roofline": {"kernel": ("gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update of the stream-scheduled factorisation, fp64 MFMA 16x16x4)"
-                                    if os.environ.get("JAICOV_POTRF_LEGACY") else
+                                    if os.environ.get("JAICOV_FACTOR_FORM") == "streams" else
                                     "chol_tile_kernel<1, false> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
                                     "persistent launch, fp64 MFMA 16x16x4, with potrf_chain_kernel's two workgroups beside it for the diagonal "
                                     "blocks; algorithmic flops = order^3 / 3; symbols as listed by rocprofv3)"),
@@ -293,7 +302,9 @@ def main():
         # library (csrc/kernel_resources.json, written by the Makefile)
         try:
             kr = json.load(open(os.path.join(ROOT, "bundle-adjustment_amd", "csrc", "kernel_resources.json")))
-            lm = ("chol_tile_kernel<1, false>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false>", "blk_T_mfma_kernel", "blk_elim_kernel",
+            # (blk_pp_gather_kernel<true, true>: the deterministic assembly; chol_tile_kernel<1, true>: the one-kernel form the PMC counters
+            # are collected on -- not kernels of the default LM pass, listed because figures of this line's family quote them)
+            lm = ("chol_tile_kernel<1, false>", "chol_tile_kernel<1, true>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false>", "blk_pp_gather_kernel<true, true>", "blk_T_mfma_kernel", "blk_elim_kernel",
                   "blk_tfix_kernel", "blk_cc", "blk_pc_gather", "rows_kernel", "backsolve_chain8_kernel", "forwardsolve_chain8_kernel", "forwardsolve_chain_kernel", "gemm_f64_kernel<0, 1, 128, 128, 0>",
                   "symv_dd_tile_kernel", "symv_dd_reduce_kernel", "blk_backsub_kernel", "damp_and_precond_kernel")
             tab = {}
@@ -342,9 +353,10 @@ def main():
             sync()
             t1 = time.perf_counter()
             # MatrixInversion.FULL as estimate() / estimateModel() run it: all of Qxx expanded from the inverse of the EO-reduced
-            # system (JAICOV_INVERT_FULL_EXPANDED); a sharded engine holds only its images' EO blocks and takes the literal route
+            # system (JAICOV_INVERT_FULL_EXPANDED); a sharded engine holds only its images' F bands and L_E^-1: they are summed over
+            # the ranks by one more all-reduce (distributed.sharded_step, jaicov_neq_expansion_buffer)
             if use_dist:
-                dx = distributed.sharded_step(eng, dist, torch.device("cuda", local), s2, invert=engine.INVERT_FULL)
+                dx = distributed.sharded_step(eng, dist, torch.device("cuda", local), s2, invert=engine.INVERT_FULL_EXPANDED)
             else:
                 eng.prepare_inverse(engine.INVERT_FULL_EXPANDED)
                 eng.build(s2, 0.0)

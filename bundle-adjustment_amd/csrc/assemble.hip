@@ -3,6 +3,8 @@
 // point-indexed blocks go out as fp64 atomics.  N is row-major LOWER (== UPLO='U' column-major).  gfx950 only.
 #include <algorithm>
 #include <cstdlib>
+#include <string.h>
+
 #include "ba_kernels.h"
 #include "gemm_f64.h"
 
@@ -928,6 +930,18 @@ hipError_t launch_schur_eliminate(hipStream_t, const DevProblem &, const int32_t
 
 hipError_t launch_schur_tfix(hipStream_t, const DevProblem &, const int32_t *, int, const double *, const double *, double, double *);
 
+// JAICOV_ASSEMBLY_FORM = t_vector | no_fork | materialise: the alternative forms of the dense-block assembly kept as second paths
+// for parity (the vector form of T = Dinv [A_c | w]; the camera-side kernels in front of the gather instead of beside it; P' written
+// out instead of formed in the gather's registers), each named by tests/test_gpu_parity.py::test_assembly_forms_give_the_same_system.
+int assembly_form() {
+    const char *e = getenv("JAICOV_ASSEMBLY_FORM");
+    if (!e) return ASSEMBLY_DEFAULT;
+    if (!strcmp(e, "t_vector")) return ASSEMBLY_T_VECTOR;
+    if (!strcmp(e, "no_fork")) return ASSEMBLY_NO_FORK;
+    if (!strcmp(e, "materialise")) return ASSEMBLY_MATERIALISE;
+    return ASSEMBLY_DEFAULT;
+}
+
 hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int32_t *blk_list, int n_list, int max_m,
                                   const int32_t *ip_list, int n_ip_list, const double *rowsA, const double *rowsW,
                                   double *T, double sigma2, double *N, double *n, const PPGather &pp, const SchurBufs &sb,
@@ -936,7 +950,8 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     const int schur = sb.active ? 1 : 0;
     // the fused gather (P' formed in registers) reads U_q from the coalesced copy Ug only: there is no row-major fallback
     if (schur && !sb.materialise && pp.pt_ip_begin && !pp.ug) return hipErrorInvalidValue;
-    const bool t_vector = getenv("JAICOV_T_VECTOR") != nullptr;
+    const int form = assembly_form();
+    const bool t_vector = form == ASSEMBLY_T_VECTOR;
     if (t_vector) hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
     else hipLaunchKernelGGL(blk_T_mfma_kernel, dim3((max_m + 255) / 256, n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T);
     DevProblem q = p;
@@ -953,15 +968,14 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     // parts of N (the gather owns the point rows from the first point column on and does not touch n) and read the same
     // finished T / U: with a side stream the three small kernels -- 0.4 ms of mostly latency -- run beside the gather, which
     // is latency-bound itself, instead of in front of it.  Their own order stays (the sums into n keep their order).
-    static const int cc_parts = getenv("JAICOV_CC_PARTS") ? std::min(16, std::max(1, atoi(getenv("JAICOV_CC_PARTS")))) : 8;
-    const bool no_fork = getenv("JAICOV_NO_ASSEMBLY_FORK") != nullptr;
+    constexpr int cc_parts = 8;
+    const bool no_fork = form == ASSEMBLY_NO_FORK;
     const bool fork = side && ev_fork && ev_join && pp.pt_ip_begin && !no_fork;
     hipStream_t cs = fork ? side : s;
-    // T' = sigma2 T - U (U' A_c) is needed by the camera-side kernels only, so it could run on their side stream beside the gather
-    // (JAICOV_TFIX_SIDE=1).  Measured at config 4: assembly 2.84 ms that way against 2.80 ms with T' in front of the fork -- the
-    // gather loses more to the company than the critical path gains.
-    static const bool tfix_main = getenv("JAICOV_TFIX_SIDE") == nullptr;
-    if (schur && tfix_main) {
+    // T' = sigma2 T - U (U' A_c) is needed by the camera-side kernels only, so it could run on their side stream beside the gather.
+    // Measured at config 4 (round 3): assembly 2.84 ms that way against 2.80 ms with T' in front of the fork -- the gather loses
+    // more to the company than the critical path gains.
+    if (schur) {
         hipError_t he = launch_schur_tfix(s, p, ip_list, n_ip_list, sb.U, sb.G, sigma2, T);
         if (he != hipSuccess) return he;
     }
@@ -970,15 +984,10 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         if (he == hipSuccess) he = hipStreamWaitEvent(side, ev_fork, 0);
         if (he != hipSuccess) return he;
     }
-    if (schur && !tfix_main) {      // T' for the camera-side kernels that follow on this stream
-        hipError_t he = launch_schur_tfix(cs, p, ip_list, n_ip_list, sb.U, sb.G, sigma2, T);
-        if (he != hipSuccess) return he;
-    }
     hipLaunchKernelGGL(blk_cc_kernel, dim3(n_list, cc_parts), dim3(256), 0, cs, p, blk_list, rowsA, T, s2, cc_partial, schur);
     hipLaunchKernelGGL(blk_cc_reduce_kernel, dim3(CC_ENT, p.n_cameras), dim3(256), 0, cs, p, blk_list, n_list, cc_parts, cc_partial, N, n, schur);
     const long tot = (long)n_ip_list * KC_LD;
-    static const bool pc_atomic = getenv("JAICOV_PC_ATOMIC") != nullptr;
-    if (pp.pt_ip_begin && !pc_atomic) {
+    if (pp.pt_ip_begin) {
         const long totp = (long)p.n_points * KC_LD;
         hipLaunchKernelGGL(blk_pc_gather_kernel, dim3((unsigned)((totp + 255) / 256)), dim3(256), 0, cs, p, pp, rowsA, T, s2, N, n, schur);
     } else

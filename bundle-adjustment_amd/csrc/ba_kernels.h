@@ -96,6 +96,9 @@ struct DenseMode {
                         const double *rowsW, double sigma2, double *N, double *n, float *gemm_ms);
 };
 
+enum { ASSEMBLY_DEFAULT = 0, ASSEMBLY_T_VECTOR = 1, ASSEMBLY_NO_FORK = 2, ASSEMBLY_MATERIALISE = 3 };
+int assembly_form();      // JAICOV_ASSEMBLY_FORM (assemble.hip): test hook for the alternative forms of the dense-block assembly
+
 // ---- slot layout ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int slot_io(const DevProblem &p, int c) { return 3 * p.n_points + 3 * c; }
 __device__ __forceinline__ int slot_dist(const DevProblem &p, int j) { return 3 * p.n_points + 3 * p.n_cameras + j; }

@@ -16,6 +16,8 @@ struct GemmArgs;
 
 constexpr int DENSE_NB = 128;      // diagonal block handled by one workgroup in LDS
 constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry at once
+enum { FACTOR_DEFAULT = 0, FACTOR_STREAMS = 1, FACTOR_TWO_STEP = 2, FACTOR_ONE_KERNEL = 3 };
+int factor_form();                 // JAICOV_FACTOR_FORM (dense.hip): test hook for the non-default forms of the factorisation
 
 struct DenseSolver {
     hipStream_t stream = nullptr;
@@ -62,7 +64,6 @@ struct DenseSolver {
     // dataflow factorisation (cholflow.hip): the whole potrf as two concurrent launches, dependencies as flags in memory
     bool flow_ready = false, flow_timed = false, flow_chain = false, flow_one_kernel = false;
     int flow_wg_off = 0;                 // offset of the per-workgroup state words in flow_flags (read by the device)
-    int flow_second = 0;                 // third chain workgroup (cholflow.hip)
     long long flow_stale_events = 0, flow_stale_confirmed = 0, flow_rescued = 0;   // flags that only the read-modify-write poll saw (fetch_info)
     std::vector<int4> flow_task_host;    // the task list (flow_report_stall)
     int reserved_cus = 8;                // CUs kept free of the update stream for the diagonal-block kernel

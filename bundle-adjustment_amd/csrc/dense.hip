@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "gemm_f64.h"
 #include "potrf_diag.h"
@@ -817,6 +818,18 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double *M, long ld, int
     }
 }
 
+// JAICOV_FACTOR_FORM = streams | two_step | one_kernel: the forms of the factorisation other than the default (dataflow, chain
+// form), each named by a case of tests/test_gpu_parity.py (test_factor_tile_by_tile, test_config3_step_against_oracle).  Read at
+// every call: the tests switch it between engines of one process.
+int factor_form() {
+    const char *e = getenv("JAICOV_FACTOR_FORM");
+    if (!e) return FACTOR_DEFAULT;
+    if (!strcmp(e, "streams")) return FACTOR_STREAMS;
+    if (!strcmp(e, "two_step")) return FACTOR_TWO_STEP;
+    if (!strcmp(e, "one_kernel")) return FACTOR_ONE_KERNEL;
+    return FACTOR_DEFAULT;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows) {
     stream = s;
@@ -843,8 +856,8 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     // (scripts/flow_trace.py, ms per factorisation dataflow / streams): order 1024 0.76 / 0.62, 2048 1.32 / 1.28,
     // 3072 1.94 / 2.00, 3712 2.37 / 2.50, 5120 3.33 / 3.75, 6144 4.07 / 4.78, 8192 5.95 / 7.92, 15104 22.3 / 26.3
     // -> from 24 block columns on.
-    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 24;
-    const bool flow_wanted = !getenv("JAICOV_POTRF_LEGACY") && nfact / 128 >= flow_from;
+    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 24;      // (the tests lower it)
+    const bool flow_wanted = factor_form() != FACTOR_STREAMS && nfact / 128 >= flow_from;
     {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -852,13 +865,11 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
         // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask is CU i/8 of XCD i%8): the trailing
         // updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.  (Reserving fewer CUs was
         // measured: one or two reserved CUs cost 5 ms per factorisation at config 4, eight cost the update 3 % of the chip.)
-        if ((nfact >= 2048 || flow_wanted) && !getenv("JAICOV_NO_CUMASK")) {
+        if (nfact >= 2048 || flow_wanted) {
             uint32_t upd[8], dia[8];
             for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
-            // reserved: CU 31 of every XCD (8 CUs, what the stream-scheduled factorisation was tuned with), or of XCD 7 only
-            reserved_cus = getenv("JAICOV_RESERVED_CUS") ? atoi(getenv("JAICOV_RESERVED_CUS")) : 8;
-            if (reserved_cus == 1) { upd[7] = 0x7FFFFFFFu; dia[7] = 0x80000000u; }
-            else { reserved_cus = 8; upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u; }
+            // reserved: CU 31 of every XCD (8 CUs; reserving one or two cost the stream-scheduled factorisation 5 ms at config 4)
+            reserved_cus = 8; upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u;
             if (hipExtStreamCreateWithCUMask(&ustream, 8, upd) != hipSuccess) ustream = nullptr;
             if (hipExtStreamCreateWithCUMask(&dstream, 8, dia) != hipSuccess) dstream = nullptr;
             if (!ustream || !dstream) {
@@ -942,18 +953,18 @@ hipEvent_t DenseSolver::next_event() {
 hipError_t DenseSolver::panel(hipStream_t st, int K0, int K1) {
     // In the tail (short trailing updates, the panel chain is the critical path) the diagonal kernel stays on the panel
     // stream: the two event hops per block cost more than the contention they avoid.
-    static const int tail_rows = getenv("JAICOV_TAIL_ROWS") ? atoi(getenv("JAICOV_TAIL_ROWS")) : 6144;
+    constexpr int tail_rows = 6144;
     for (int k = K0; k < K1; k++) {
         double *Akk = L + (long)(k * 128) * ld + k * 128;
         const int rows_k = n - k * 128;
         // ... except for the first block of a panel: it becomes ready at the moment the trailing update is launched, and a
         // workgroup that wants a whole CU's LDS then waits for the update's first tiles to retire (130 us instead of 49)
-        static const bool first_split = !(getenv("JAICOV_TAIL_FIRST_SPLIT") && atoi(getenv("JAICOV_TAIL_FIRST_SPLIT")) == 0);
+        constexpr bool first_split = true;
         // (only while the update still has more workgroups than the chip has slots: 31 tile rows = 496 tiles)
         const bool split = dstream != nullptr && st == pstream && (rows_k > tail_rows || (first_split && k == K0 && rows_k > 4096));
         // While the trailing update still hides the panel (many rows left) the panel GEMMs take the 128-tile: it costs
         // the update fewer CU slots per flop than the 64-tile latency variant, which is for the critical-path regime.
-        static const int bulk_rows = getenv("JAICOV_BULK_ROWS") ? atoi(getenv("JAICOV_BULK_ROWS")) : 9216;
+        constexpr int bulk_rows = 9216;
         // in between (the update still shares the chip) the 64-tile; the 32-tile only once the panel runs alone
         const int small = (st == pstream && rows_k > bulk_rows) ? 0 : ((st == pstream && rows_k > tail_rows) ? 1 : -1);
         if (k > K0) {
@@ -1009,11 +1020,7 @@ hipError_t DenseSolver::timed_gemm(hipStream_t st, const GemmArgs &u, double flo
 
 int DenseSolver::first_panel_cols() const {
     const int nb = nfact / 128;
-    int w = getenv("JAICOV_NBO") ? atoi(getenv("JAICOV_NBO")) : nbo;
-    const int big_rows = getenv("JAICOV_NBO_BIG_ROWS") ? atoi(getenv("JAICOV_NBO_BIG_ROWS")) : 1 << 30;
-    const int small_rows = getenv("JAICOV_NBO_SMALL_ROWS") ? atoi(getenv("JAICOV_NBO_SMALL_ROWS")) : 0;
-    const int bo = w / 128 > 0 ? w / 128 : 1;
-    const int k = n > big_rows ? 2 * bo : (n > small_rows ? bo : (bo > 1 ? bo / 2 : 1));
+    const int k = nbo / 128 > 0 ? nbo / 128 : 1;
     return 128 * (k < nb ? k : nb);
 }
 
@@ -1034,18 +1041,11 @@ hipError_t DenseSolver::potrf(hipEvent_t first_ready, hipEvent_t all_ready) {
 
 hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_ready) {
     const int nb = nfact / 128;   // diagonal blocks; rows run to n (the right-hand-side rows below the matrix included)
-    if (const char *e = getenv("JAICOV_NBO")) nbo = atoi(e);
-    // Panel width: wide panels (K = 2 nbo) make the trailing update more efficient while it dominates (many rows left),
-    // narrow ones shorten the panel chain once that is the critical path.
-    static const int big_rows = getenv("JAICOV_NBO_BIG_ROWS") ? atoi(getenv("JAICOV_NBO_BIG_ROWS")) : 1 << 30;
-    static const int small_rows = getenv("JAICOV_NBO_SMALL_ROWS") ? atoi(getenv("JAICOV_NBO_SMALL_ROWS")) : 0;
+    // Panel width: one width for the whole factorisation (wide panels while many rows remain, narrow ones in the tail: measured
+    // flat +- 0.3 ms at config 4, DESIGN_HISTORY.md)
     const int bo = nbo / 128 > 0 ? nbo / 128 : 1;
-    auto width = [&](int K) {
-        const int rows = n - K * 128;
-        return rows > big_rows ? 2 * bo : (rows > small_rows ? bo : (bo > 1 ? bo / 2 : 1));
-    };
-    static const bool no_la = getenv("JAICOV_NO_LOOKAHEAD") != nullptr;
-    const bool la = lookahead && !no_la && pstream != nullptr && nb > bo;
+    auto width = [&](int) { return bo; };
+    const bool la = lookahead && pstream != nullptr && nb > bo;
     ev_used = 0;
     hipStream_t sp = la ? pstream : stream;                 // panel GEMMs
     hipStream_t su = la && ustream ? ustream : stream;      // trailing updates (all CUs but the reserved ones)
@@ -1065,67 +1065,6 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
     HIPCHK(panel(sp, 0, K1));
     hipEvent_t e_panel = next_event();
     if (la) HIPCHK(hipEventRecord(e_panel, sp));
-    // Alternative schedule with the next panel's columns updated early (JAICOV_SPLIT_UPDATE=1; measured equal to the
-    // default below within +-0.2 ms at config 4, so the simpler one stays the default).  With L_k the panel
-    // factored last, [K1,K2) the next panel and [K2,K3) the one after:
-    //   update stream:  (b1)_k  columns [K2,K3) -= L_k ...   then   (b2)_k  lower square from K3 on -= L_k ...
-    //   panel stream :  panel [K1,K2)  ->  (a)_{k+1}  columns [K2,K3) -= L_{k+1} ...  (after (b1)_k)  ->  panel [K2,K3)  -> ...
-    // so the panel stream never waits for the bulk of an update, and the narrow GEMM (a), which cannot fill the chip once
-    // fewer than ~7000 rows are left, runs beside (b2) instead of alone between two updates.  Updates of one tile by
-    // different panels commute but must not overlap in time: (b1)_k and (a)_{k+1} are ordered by an event, everything
-    // else by stream order.
-    static const bool split_update = getenv("JAICOV_SPLIT_UPDATE") && atoi(getenv("JAICOV_SPLIT_UPDATE")) != 0;
-    if (la && split_update) {
-        auto rect = [&](hipStream_t st, int Ka, int Kb, int C0, int C1) -> hipError_t {
-            // C[rows >= C0, cols [C0,C1)] -= L[rows >= C0, cols [Ka,Kb)] * L[rows [C0,C1), cols [Ka,Kb)]'
-            GemmArgs a{};
-            a.A = L + (long)(C0 * 128) * ld + Ka * 128; a.lda = ld; a.B = a.A; a.ldb = ld;
-            a.C = L + (long)(C0 * 128) * ld + C0 * 128; a.ldc = ld;
-            a.M = n - C0 * 128; a.N = (C1 - C0) * 128; a.K = (Kb - Ka) * 128; a.alpha = -1.0; a.beta = 1.0; a.lower_only = 0;
-            a.kmode = KMODE_FULL;
-            return gemm_f64(st, LAY_KC, LAY_KC, a);
-        };
-        auto next_end = [&](int K) { return (K + width(K) < nb) ? K + width(K) : nb; };
-        if (K1 < nb) {   // (a)_0 on the update stream, as there is no (b1) before it
-            HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
-            HIPCHK(rect(su, K0, K1, K1, next_end(K1)));
-            hipEvent_t e = next_event();
-            HIPCHK(hipEventRecord(e, su));
-            HIPCHK(hipStreamWaitEvent(sp, e, 0));
-        }
-        while (K1 < nb) {
-            const int K2 = next_end(K1);
-            HIPCHK(panel(sp, K1, K2));                       // its columns carry every earlier panel's update by now
-            hipEvent_t e_next = next_event();
-            HIPCHK(hipEventRecord(e_next, sp));
-            if (K2 < nb) {
-                const int K3 = next_end(K2);
-                HIPCHK(hipStreamWaitEvent(su, e_panel, 0));  // L_k = panel [K0,K1) is complete
-                HIPCHK(rect(su, K0, K1, K2, K3));            // (b1)_k
-                hipEvent_t e_b1 = next_event();
-                HIPCHK(hipEventRecord(e_b1, su));
-                const int rows = n - K3 * 128;
-                if (rows > 0 && K3 < nb) {                   // (b2)_k
-                    const int Kw = (K1 - K0) * 128;
-                    GemmArgs u{};
-                    u.A = L + (long)(K3 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
-                    u.C = L + (long)(K3 * 128) * ld + K3 * 128; u.ldc = ld;
-                    u.M = rows; u.N = rows; u.K = Kw; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
-                    static const bool no_maps = getenv("JAICOV_NO_XCD_MAP") != nullptr;
-                    if (xcd_maps && !no_maps && rows / 128 >= 24) {
-                        auto it = tile_maps.find(rows / 128);
-                        if (it != tile_maps.end()) { u.tile_map = it->second.first; u.n_map = it->second.second; }
-                    }
-                    HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
-                }
-                HIPCHK(hipStreamWaitEvent(sp, e_b1, 0));
-                HIPCHK(rect(sp, K1, K2, K2, K3));            // (a)_{k+1}, behind panel [K1,K2) on its stream
-            }
-            e_panel = e_next;
-            K0 = K1;
-            K1 = K2;
-        }
-    }
     while (K1 < nb) {
         const int K2 = (K1 + width(K1) < nb) ? K1 + width(K1) : nb;     // end of the next panel
         if (la) HIPCHK(hipStreamWaitEvent(su, e_panel, 0));
@@ -1153,8 +1092,7 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
             u.A = L + (long)(K2 * 128) * ld + K0 * 128; u.lda = ld; u.B = u.A; u.ldb = ld;
             u.C = L + (long)(K2 * 128) * ld + K2 * 128; u.ldc = ld;
             u.M = rows; u.N = rows; u.K = Kw; u.alpha = -1.0; u.beta = 1.0; u.lower_only = 1; u.kmode = KMODE_FULL;
-            static const bool no_maps = getenv("JAICOV_NO_XCD_MAP") != nullptr;
-            if (xcd_maps && !no_maps && rows / 128 >= 24) {
+            if (xcd_maps && rows / 128 >= 24) {
                 const int T = rows / 128;
                 auto it = tile_maps.find(T);
                 if (it != tile_maps.end()) {
@@ -1162,11 +1100,7 @@ hipError_t DenseSolver::potrf_streams(hipEvent_t first_ready, hipEvent_t all_rea
                     u.n_map = it->second.second;
                 }
             }
-            // tail: the panel chain is the critical path and its workgroups queue behind the update's; 64-tiles retire 4x
-            // as often (the update itself is not on the critical path there)
-            static const int upd64_rows = getenv("JAICOV_UPDATE64_ROWS") ? atoi(getenv("JAICOV_UPDATE64_ROWS")) : 0;
-            const int small_u = (la && rows <= upd64_rows) ? 1 : 0;
-            HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw, small_u));
+            HIPCHK(timed_gemm(su, u, (double)rows * ((double)rows + 1.0) * (double)Kw));
         }
         K0 = K1;
         K1 = K2;
@@ -1193,7 +1127,6 @@ static int chain8_min_nb() {         // (read at every call: the tests lower it)
 // the backward chain for one right-hand side: two workgroups per block column when the whole grid is resident at once
 bool DenseSolver::chain8_split() const {
     const int nb = nfact / 128;
-    static const bool nosplit = getenv("JAICOV_CHAIN_NO_SPLIT") != nullptr;
     static int cus = 0;
     if (cus == 0) {
         int dev = 0;
@@ -1201,7 +1134,7 @@ bool DenseSolver::chain8_split() const {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) cus = pr.multiProcessorCount;
         if (cus <= 0) cus = 1;
     }
-    return !nosplit && xch && nb >= 8 && 2 * nb <= cus;
+    return xch && nb >= 8 && 2 * nb <= cus;
 }
 
 hipError_t DenseSolver::launch_chain8(const double *Zrow, double *X, const int *abort_word, long long *trace) {
@@ -1238,7 +1171,7 @@ hipError_t DenseSolver::premultiply() {
         f.batch_sum_limit = nb - 1;
         // the Ft blocks are needed by the forward chain of the refinement only: on the side stream, beside the first backward chain
         // and the residual (solve_rhs waits for pm_done)
-        static const bool side = !getenv("JAICOV_PM_ONE_STREAM");
+        constexpr bool side = true;
         if (side && pstream && pm_e0 && pm_done) {
             HIPCHK(hipEventRecord(pm_e0, stream));
             HIPCHK(hipStreamWaitEvent(pstream, pm_e0, 0));
@@ -1258,8 +1191,7 @@ hipError_t DenseSolver::backsolve_aug(double *X, long xs, int nrhs) {
     const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nrhs * xs * sizeof(double), stream));   // "not yet published"
     const int *ab = flow_ready ? flow_flags + 1 : nullptr;      // cholflow.hip FLOW_ABORT
-    static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;      // the chains without pre-multiplied last blocks
-    if (nrhs <= 1 && pm && !plain && nb >= chain8_min_nb()) {
+    if (nrhs <= 1 && pm && nb >= chain8_min_nb()) {
         HIPCHK(premultiply());
         HIPCHK(launch_chain8(rhs_row(0), X, ab, nullptr));
     } else if (nrhs <= 1) hipLaunchKernelGGL(backsolve_chain_kernel<1>, dim3(nb), dim3(256), 0, stream, L, ld, invd, rhs_row(0), ld, X, xs, nb, nrhs, ab);
@@ -1275,8 +1207,7 @@ hipError_t DenseSolver::solve_rhs(const double *b, double *tmp, double *X) {
     const int nb = nfact / 128;
     HIPCHK(hipMemsetAsync(tmp, 0xFF, (size_t)nfact * sizeof(double), stream));
     HIPCHK(hipMemsetAsync(X, 0xFF, (size_t)nfact * sizeof(double), stream));
-    static const bool plain = getenv("JAICOV_CHAIN_PLAIN") != nullptr;
-    if (pm && !plain && nb >= chain8_min_nb()) {
+    if (pm && nb >= chain8_min_nb()) {
         HIPCHK(premultiply());
         static const bool tracing = getenv("JAICOV_CHAIN_TRACE") != nullptr;     // development: link times of the backward chain on stderr
         long long *tr = nullptr;
@@ -1341,7 +1272,7 @@ const int2 *DenseSolver::trtri_tile_order(int tm, int tn, int kind) {
 hipError_t DenseSolver::trtri() {
     const int nb = nfact / 128;
     if (!Q) return hipErrorInvalidValue;
-    static const bool lpt = !getenv("JAICOV_TRTRI_ROWMAJOR");
+    constexpr bool lpt = true;      // longest k-range first (row-major order: 24.7 instead of 18.5 ms at config 4)
     HIPCHK(hipMemsetAsync(W, 0, (size_t)n * ld * sizeof(double), stream));
     hipLaunchKernelGGL(copy_diag_blocks_kernel, dim3(nb), dim3(256), 0, stream, invd, W, ld);
     for (int h = 1; h < nb; h *= 2) {

@@ -95,13 +95,12 @@ hipError_t DenseMode::init(int max_m, int max_k1, int n_blocks, bool single) {
     kpad = ((max_k1 + 127) / 128) * 128;
     // images per launch: the lower-triangular S launch has 78 tiles per image at config 4, so a small batch leaves
     // the last of its ceil(78*batch/512) rounds of workgroups partly empty (batch 16: 2.44 rounds -> 3)
-    // and a large one amortises it: 55.4 TFLOP/s at 16, 60.7 at 32, 62.8 at 500 (scripts/dm_batch_sweep.py).
+    // and a large one amortises it: 55.4 TFLOP/s at 16, 60.7 at 32, 62.8 at 500 (round 2's sweep).
     // Default: as many images as fit 32 GB of workspace (all 500 of config 4: 26 GB of the 288 GB).
     const size_t es = fp32 ? sizeof(float) : sizeof(double);
     const size_t per_image = ((size_t)mpad * mpad + 2 * (size_t)mpad * kpad + (size_t)kpad * kpad) * es;
     long want = (long)(((size_t)32 << 30) / per_image);
     if (want < 1) want = 1;
-    if (const char *e = getenv("JAICOV_DM_BATCH")) want = atoi(e) > 0 ? atoi(e) : want;
     batch = n_blocks < want ? (n_blocks > 0 ? n_blocks : 1) : (int)want;
     hipError_t he;
     if ((he = hipMalloc(&Ppad, (size_t)batch * mpad * mpad * es)) != hipSuccess) return he;

@@ -227,7 +227,10 @@ struct jaicov_engine {
     bool dense_mode = false;
     double dm_flops_per_pass = 0.0, dm_stat_passes = 0.0, dm_stat_ms = 0.0, dm_stat_flops = 0.0;
     int inverse_mode_next = 0;       // JAICOV_INVERT_* announced for the solve after the next build
-    bool all_images = true;          // this engine accumulates every image (not a shard): FULL_EXPANDED needs every image's U, L_E
+    bool all_images = true;          // this engine accumulates every image (not a shard): FULL_EXPANDED needs every image's F band and L_E ...
+    double *d_expF = nullptr;        // ... a shard's caller sums them over the ranks: [F (6 images padded x reduced order padded) | Linv (36 per image)]
+    size_t expF_len = 0;
+    bool exp_ready = false;          // d_expF belongs to the system accumulated last and has been handed out (jaicov_neq_expansion_buffer)
     bool solver_has_Q = false;       // solver.Q alone is allocated (target of the expansion)
     int q_order = 0;                 // order of the cofactor matrix on the device (U, or e0 for the reduced one)
     bool q_reduced = false, solverS_has_inverse = false;
@@ -460,6 +463,7 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     if (e->ev_r0) hipEventDestroy(e->ev_r0);
     if (e->ev_r1) hipEventDestroy(e->ev_r1);
     if (e->d_refP) hipFree(e->d_refP);
+    if (e->d_expF) hipFree(e->d_expF);
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -471,9 +475,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     std::vector<double> pv_x, pv_y, pv_vx, pv_vy, pv_rho;
     HIPE(e, hipSetDevice(e->device));
     e->deterministic = e->opts.deterministic != 0;
-    if (const char *dv = getenv("JAICOV_DETERMINISTIC")) e->deterministic = atoi(dv) != 0;
     e->refine_steps = e->opts.refinement == 0 ? 1 : (e->opts.refinement < 0 ? 0 : std::min(e->opts.refinement, 4));
-    if (const char *rv = getenv("JAICOV_REFINE")) e->refine_steps = std::max(0, std::min(atoi(rv), 4));
     hipDeviceProp_t prop;
     HIPE(e, hipGetDeviceProperties(&prop, e->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -555,8 +557,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     std::vector<int64_t> syn_off;
     e->h_caller_block.clear();
     {
-        const char *env = getenv("JAICOV_SCHUR");
-        bool ok = !(env && env[0] == '0') && e->opts.ordinary_group_elimination >= 0 && e->opts.assembly_mode == 0 && D->n_images > 0;
+        bool ok = e->opts.ordinary_group_elimination >= 0 && e->opts.assembly_mode == 0 && D->n_images > 0;
         const int e0 = D->n_images > 0 ? D->eo_col[0] : -1;
         ok = ok && e0 >= d && e0 + 6 * D->n_images == U;
         for (int i = 0; ok && i < 6 * D->n_images; i++) ok = D->eo_col[i] == e0 + i;
@@ -723,7 +724,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     if ((rc = upload(e, blk_list.data(), blk_list.size(), &tmp32))) return rc; e->d_blk_list = (int32_t *)tmp32;
     if ((rc = upload(e, blk_ip_list.data(), blk_ip_list.size(), &tmp32))) return rc; e->d_blk_ip_list = (int32_t *)tmp32;
     if ((rc = upload(e, in_block.data(), in_block.size(), &tmp8))) return rc; e->d_in_block = (uint8_t *)tmp8;
-    if (!blk_ip_list.empty() && !getenv("JAICOV_PP_ATOMIC")) {
+    if (!blk_ip_list.empty()) {
         // point -> block image points (CSR, image order) for the atomics-free point x point gather
         std::vector<int32_t> cnt(D->n_points + 1, 0), blk_of_ip(D->n_image_points, -1);
         for (size_t t = 0; t < blk_list.size(); t++)
@@ -752,12 +753,11 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             for (int ip : blk_ip_list)
                 for (int a = 0; a < 3; a++) ipcol[(size_t)3 * ip + a] = D->point_col[3 * D->ip_point[ip] + a];
             // per record and column chunk: the range of partner positions (the block is stored in column order)
-            int cw_rt = getenv("JAICOV_PP_CW") ? atoi(getenv("JAICOV_PP_CW")) : PP_CW;
-            cw_rt = std::max(64, std::min(cw_rt, 6400)) / 4 * 4;           // 3 * cw doubles of LDS (<= 150 KB), quarters for the DET form
+            const int cw_rt = std::max(64, std::min(PP_CW, 6400)) / 4 * 4;  // 3 * cw doubles of LDS (<= 150 KB), quarters for the DET form
             e->pp.cw = cw_rt;
             // XCD-partitioned block order (assemble.hip): measured no faster (3.24 vs 3.26 ms at 960 columns, slower where the chunks
             // do not divide evenly over eight XCDs) and FETCH_SIZE fell by 6 % only: the partner records are not what the kernel waits for
-            e->pp.xcd_map = getenv("JAICOV_PP_XCD") ? atoi(getenv("JAICOV_PP_XCD")) : 0;
+            e->pp.xcd_map = 0;
             const int n_chunks = (cmax - cmin + cw_rt) / cw_rt;
             const int NOCOL = 1 << 30;
             std::vector<int32_t> lo_col(D->n_image_points, NOCOL), hi_col(D->n_image_points, -1);
@@ -809,7 +809,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
                 }
                 bool all = true;
                 for (char f : is_pt) all = all && f;
-                e->pp_plain_ok = all && !getenv("JAICOV_PP_RMW");
+                e->pp_plain_ok = all;
             }
         }
     }
@@ -886,12 +886,11 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     // ---- EO pre-elimination is possible when every image point sits in an image block, the EO columns are the
     //      trailing columns e0 + 6*image + k, and no directly observed parameter is an EO parameter ------------------
     {
-        const char *env = getenv("JAICOV_SCHUR");
         // Eligibility is a property of the WHOLE problem, not of this engine's image range: every rank of a sharded run must
         // reach the same decision, or their reduce buffers differ in length (and only some ranks enter the EO exchange).
         size_t n_in_block = 0;
         for (int ip = 0; ip < D->n_image_points; ip++) n_in_block += in_block[ip] ? 1 : 0;
-        bool ok = !(env && env[0] == '0') && D->n_images > 0 && D->n_image_blocks > 0 && n_in_block == (size_t)D->n_image_points;
+        bool ok = D->n_images > 0 && D->n_image_blocks > 0 && n_in_block == (size_t)D->n_image_points;
         if ((e->opts.assembly_mode == 1 || e->opts.assembly_mode == 2) && e->n_blk_list > 0) {   // densified MFMA contraction of the image groups (densemode.hip)
             int max_k1 = 0;
             for (int g : blk_list) {
@@ -917,7 +916,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if ((rc = dalloc(e, (size_t)36 * D->n_images, &e->sb.Linv, true))) return rc;
             if ((rc = dalloc(e, (size_t)6 * SCHUR_GLD * D->n_images, &e->sb.G, true))) return rc;
             // P' = sigma2 Dinv - U U' is formed inside the point x point gather; a copy in memory (4 GB at config 4) only on request
-            e->sb.materialise = (getenv("JAICOV_PP_MATERIALISE") || getenv("JAICOV_PP_ATOMIC")) ? 1 : 0;
+            e->sb.materialise = assembly_form() == ASSEMBLY_MATERIALISE ? 1 : 0;     // test hook (JAICOV_ASSEMBLY_FORM, assemble.hip)
             if (e->sb.materialise && (rc = dalloc(e, (size_t)std::max<int64_t>(w_total_saved, 1), &e->sb.Pp))) return rc;
             if ((rc = dalloc(e, (size_t)6 * D->n_images, &e->d_xE, true))) return rc;
             if (e->opts.reduced_reference_quirk && (rc = dalloc(e, (size_t)6 * D->n_images, &e->sb.xq, true))) return rc;
@@ -1047,6 +1046,7 @@ extern "C" int jaicov_neq_accumulate(jaicov_engine *e, double sigma2) {
         HIPE(e, launch_assemble_small(e->stream, e->p, e->d_seg_begin, e->d_seg_end, e->n_seg, e->d_rowsA, e->d_rowsW, sigma2, e->d_N, e->d_n));
     if (e->opts.apply_shared) HIPE(e, launch_shared_groups(e->stream, e->p, e->d_vals, sigma2, e->d_N, e->d_n, nullptr, nullptr));
     HIPE(e, hipEventRecord(e->ev[2], e->stream));
+    e->exp_ready = false;            // the expansion buffer of an earlier pass is stale now
     e->state = jaicov_engine::ST_ACCUMULATED;
     e->have_Q = false;
     return JAICOV_OK;
@@ -1136,9 +1136,10 @@ static int ensure_inverse_buffers(jaicov_engine *e, bool reduced_system) {
 }
 
 // FULL_EXPANDED is FULL wherever the expansion cannot be done: no EO pre-elimination, or an engine that sees a shard of the images
+// and whose caller has not promised to sum the expansion's inputs over the ranks (engine option expansion_exchange)
 static int effective_invert(const jaicov_engine *e, int invert) {
     if (invert != JAICOV_INVERT_FULL_EXPANDED) return invert;
-    if (!(e->schur_ok && e->all_images && e->solverS_ready && !getenv("JAICOV_FULL_LITERAL"))) return JAICOV_INVERT_FULL;
+    if (!(e->schur_ok && (e->all_images || e->opts.expansion_exchange != 0) && e->solverS_ready)) return JAICOV_INVERT_FULL;
     // the expansion's workspace is the reduced solver's W square: F and T1 ([6 images, padded] x order) and T2 must fit (they do
     // unless the exterior orientations outnumber the other unknowns several times over: then the literal route is taken)
     const size_t I6p = ((size_t)6 * e->p.n_images + 127) / 128 * 128, Up = (size_t)e->solverS.nfact;
@@ -1286,13 +1287,11 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     // V to the host, scaled + row-normalised datum rows Bh = R B V (NES:82-91 scaling of the border)
     // This round trip stays even where nothing of it is needed before the factorisation (d = 0): with the host running ahead of
     // the assembly -- enqueuing the factorisation and spinning in its residency handshake while the assembly kernels still run --
-    // every pass was 0.6 ms SLOWER (assembly +0.19, factorisation +0.4; measured A/B, JAICOV_EARLY_ENQUEUE=1 brings it back).
+    // every pass was 0.6 ms SLOWER (assembly +0.19, factorisation +0.4; measured A/B in round 3).
     // What d = 0 does save is the round trip between the substitution and the first refinement step (`fast` below).
-    const bool fast = d == 0 && !getenv("JAICOV_NO_FAST_SOLVE");
-    static const bool early_enqueue = getenv("JAICOV_EARLY_ENQUEUE") != nullptr;
-    const bool presync = !(fast && early_enqueue);
+    const bool fast = d == 0;
     int hinfo = 0;   // status of the per-image EO eliminations, fetched in the same round trip
-    if (presync) {
+    {
         HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         if (schur) HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
@@ -1316,7 +1315,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     // right-hand sides: row 0 = V n, rows 1..d = Bh.  They are the extra rows below the matrix, so the factorisation
     // itself carries out the forward substitution (dense.hip).
     const int vs = Up;   // stride between the solution vectors (the solver's order)
-    const bool fused = slv.flow_ready && !getenv("JAICOV_NO_FUSED_SCALE");
+    const bool fused = slv.flow_ready;
     const int c1 = std::min(slv.first_panel_cols(), Up);
     // dataflow factorisation: the tile kernel reads N itself and scales on the fly (no copy of the matrix at all);
     // stream-scheduled one: the columns of the first panel go first, together with the right-hand sides; the panel then
@@ -1371,10 +1370,6 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         HIPE(e, hipMemcpyAsync(delta0.data(), d_delta, delta0.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         fast_refined = true;
     }
-    if (!presync) {
-        HIPE(e, hipMemcpyAsync(e->h_V.data(), e->d_V, Upad * sizeof(double), hipMemcpyDeviceToHost, e->stream));
-        if (schur) HIPE(e, hipMemcpyAsync(&hinfo, e->sb.info, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-    }
     info = slv.fetch_info();
     if (info == -9 && attempt < 2) {
         ++e->flow_retries;
@@ -1383,7 +1378,6 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     }
     break;
     }
-    if (!presync && hinfo != 0) FAIL(e, JAICOV_ERR_SINGULAR, "exterior orientation block of image " + std::to_string(hinfo - 1000000) + " is not positive definite");
     if (info < 0) FAIL(e, JAICOV_ERR_DEVICE, "factorisation did not complete on the device (code " + std::to_string(info) + ")");
     if (info != 0) FAIL(e, JAICOV_ERR_SINGULAR, "normal-equation matrix is singular / not positive definite at pivot " + std::to_string(info));
     // ---- rank-d border algebra on the host ---------------------------------------------------------------------
@@ -1562,8 +1556,15 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
             if ((size_t)I6p * ((size_t)2 * Up + I6p) > (size_t)slv.n * slv.ld)
                 FAIL(e, JAICOV_ERR_UNSUPPORTED, "FULL_EXPANDED: more exterior orientations than the workspace holds; use JAICOV_INVERT_FULL");
             double *Fm = slv.W, *T1 = Fm + (size_t)I6p * Up, *T2 = T1 + (size_t)I6p * Up;
-            HIPE(e, hipMemsetAsync(Fm, 0, (size_t)I6p * Up * sizeof(double), e->stream));
-            HIPE(e, launch_schur_expand_f(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->sb.U, e->sb.Linv, e->sb.G, Fm, (long)Up));
+            if (e->all_images) {
+                HIPE(e, hipMemsetAsync(Fm, 0, (size_t)I6p * Up * sizeof(double), e->stream));
+                HIPE(e, launch_schur_expand_f(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->sb.U, e->sb.Linv, e->sb.G, Fm, (long)Up));
+            } else {      // a shard: F and L_E^-1 of EVERY image, summed over the ranks by the caller (jaicov_neq_expansion_buffer)
+                if (!e->exp_ready || e->expF_len != (size_t)I6p * Up + (size_t)36 * e->p.n_images)
+                    FAIL(e, JAICOV_ERR_BAD_STATE, "FULL_EXPANDED on a sharded engine: all-reduce jaicov_neq_expansion_buffer() between accumulate and solve");
+                HIPE(e, hipMemcpyAsync(Fm, e->d_expF, (size_t)I6p * Up * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+                HIPE(e, hipMemcpyAsync(e->sb.Linv, e->d_expF + (size_t)I6p * Up, (size_t)36 * e->p.n_images * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+            }
             HIPE(e, slv.symmetrize(slv.Q));
             GemmArgs g1{};
             g1.A = Fm; g1.lda = Up; g1.B = slv.Q; g1.ldb = ld; g1.C = T1; g1.ldc = Up;
@@ -1599,6 +1600,31 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     hipEventElapsedTime(&ms, e->ev[6], e->ev[7]); e->timings[5] = std::max(0.f, ms - refine_ms);   // the refinement sits between these events: counted under [4]
     hipEventElapsedTime(&ms, e->ev[0], e->ev[7]); e->timings[7] = ms;
     e->state = jaicov_engine::ST_SOLVED;
+    return JAICOV_OK;
+}
+
+extern "C" int jaicov_neq_expansion_buffer(jaicov_engine *e, void **device_ptr, size_t *count) {
+    if (!e || !device_ptr || !count) return JAICOV_ERR_BAD_ARGUMENT;
+    if (e->state != jaicov_engine::ST_ACCUMULATED || !e->schur_active || !e->solverS_ready)
+        FAIL(e, JAICOV_ERR_BAD_STATE, "expansion buffer: accumulate a pre-eliminated system first (prepare_inverse(JAICOV_INVERT_FULL_EXPANDED))");
+    HIPE(e, hipSetDevice(e->device));
+    const size_t I6p = ((size_t)6 * e->p.n_images + 127) / 128 * 128, Up = (size_t)e->solverS.nfact;
+    const size_t len = I6p * Up + (size_t)36 * e->p.n_images;
+    if (!e->d_expF || e->expF_len != len) {
+        if (e->d_expF) hipFree(e->d_expF);
+        e->d_expF = nullptr;
+        HIPE(e, hipMalloc(&e->d_expF, len * sizeof(double)));
+        e->expF_len = len;
+    }
+    { int rr = ensure_rows(e); if (rr) return rr; }
+    HIPE(e, hipMemsetAsync(e->d_expF, 0, I6p * Up * sizeof(double), e->stream));       // foreign images' bands: zero
+    HIPE(e, launch_schur_expand_f(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->sb.U, e->sb.Linv, e->sb.G, e->d_expF, (long)Up));
+    // L_E^-1: written for this engine's images only (blk_elim_kernel), zero elsewhere since create
+    HIPE(e, hipMemcpyAsync(e->d_expF + I6p * Up, e->sb.Linv, (size_t)36 * e->p.n_images * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+    HIPE(e, hipStreamSynchronize(e->stream));
+    e->exp_ready = true;
+    *device_ptr = e->d_expF;
+    *count = len;
     return JAICOV_OK;
 }
 
@@ -1766,6 +1792,7 @@ extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t 
         stats[9] = (double)(e->solver.flow_rescued + e->solverS.flow_rescued);
     }
     if (n >= 11) stats[10] = e->last_refine_correction;
+    if (n >= 12) stats[11] = (double)e->refine_steps;      // refinement steps per solve the engine actually runs (option `refinement`, clamped)
     if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = e->dm_stat_passes = e->dm_stat_ms = e->dm_stat_flops = 0.0;
     return JAICOV_OK;
 }
@@ -2045,7 +2072,7 @@ extern "C" int jaicov_debug_potrf_bench(int n, int reps, double *ms_out, long lo
             hipEventElapsedTime(&ms, e0, e1);
             ms_out[r] = ms;
             if (info < 0) { status = JAICOV_ERR_DEVICE; break; }
-            if (info != 0 && !getenv("JAICOV_FLOW_FAKE_A")) { status = JAICOV_ERR_SINGULAR; break; }
+            if (info != 0) { status = JAICOV_ERR_SINGULAR; break; }
         }
         if (status == JAICOV_OK && trace_out && ds.flow_trace) {
             const long long cnt = std::min<long long>(trace_cap, ((long long)ds.flow_tasks + n / 128) * 8);   // per task, then per block column (chain kernel)

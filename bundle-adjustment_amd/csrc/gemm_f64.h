@@ -307,8 +307,7 @@ inline hipError_t gemm_f64(hipStream_t s, int alay, int blay, const GemmArgs &g,
     if (can_small && (small_tiles > 0 || (small_tiles < 0 && tiles * batch < GEMM_SMALL_TILE_LIMIT))) {
         // even the 64-tile leaves most SIMDs idle when only a few block rows remain; a wave then spends its k-step in
         // 16 dependent-issue MFMAs.  The 32-tile (one MFMA tile per wave) cuts that to 4.
-        static const int tiny_limit = getenv("JAICOV_TINY_LIMIT") ? atoi(getenv("JAICOV_TINY_LIMIT")) : GEMM_TINY_TILE_LIMIT;
-        const bool tiny = small_tiles < 0 && tiles * batch * 4 < tiny_limit;
+        const bool tiny = small_tiles < 0 && tiles * batch * 4 < GEMM_TINY_TILE_LIMIT;
         if (g.C == g.A || g.C == g.B) {   // in place (one column tile): keep the whole row of C in one workgroup
             if (tn != 1) return hipErrorInvalidValue;
             if (tiny) {

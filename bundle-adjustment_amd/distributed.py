@@ -98,6 +98,14 @@ def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
     eng.accumulate(sigma2, lam)
     _check_same_buffer_on_all_ranks(eng, dist, device)
     allreduce_engine_buffer(eng, dist, device)
+    if int(invert) == 3 and getattr(eng, "expansion_exchange", False) and eng.reduced_order() < eng.U:
+        # MatrixInversion.FULL expanded from the reduced inverse (BA:268-271): every rank holds the F bands and L_E^-1 of its own
+        # images only; one more all-reduce (zeros elsewhere) gives every rank all of them (371 MB at config 4)
+        ptr, cnt = eng.expansion_buffer()
+        t = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
+        dist.all_reduce(t)
+        if torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
     eng.finalize(sigma2, lam)
     dx = eng.solve(invert)
     e0 = eng.reduced_order()

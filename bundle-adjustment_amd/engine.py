@@ -28,7 +28,7 @@ EXPORTS = [
     "jaicov_neq_get_cofactor_sub", "jaicov_neq_get_dispersion_sub", "jaicov_neq_get_rows", "jaicov_neq_estimate", "jaicov_neq_last_timings",
     "jaicov_neq_set_profiling", "jaicov_neq_kernel_stats", "jaicov_neq_cancel",
     "jaicov_dense_spd_solve_packed", "jaicov_dense_gemm", "jaicov_neq_eo_step_buffer",
-    "jaicov_neq_create_timings", "jaicov_neq_get_block_weight",
+    "jaicov_neq_create_timings", "jaicov_neq_get_block_weight", "jaicov_neq_expansion_buffer",
 ]
 
 KROW = 32  # 12 + JAICOV_MAX_DIST_PER_CAMERA
@@ -50,7 +50,7 @@ class EngineOptions(C.Structure):
                 ("image_end", C.c_int32), ("apply_shared", C.c_int32), ("assembly_mode", C.c_int32),
                 ("block_size", C.c_int32), ("reduced_reference_quirk", C.c_int32), ("deterministic", C.c_int32), ("refinement", C.c_int32),
                 ("ordinary_group_elimination", C.c_int32), ("dispersion_refinement", C.c_int32),
-                ("reserved", C.c_int32 * 3)]
+                ("expansion_exchange", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class EstimateOptions(C.Structure):
@@ -105,6 +105,7 @@ def load_library():
     L.jaicov_neq_reduce_buffer_async.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(vp)]
     L.jaicov_neq_solve.argtypes = [vp, C.c_int, _pd]
     L.jaicov_neq_eo_step_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.jaicov_neq_expansion_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.jaicov_neq_omega.argtypes = [vp, C.c_double, _pd, _pd]
     L.jaicov_neq_update.argtypes = [vp, _pd, _pd]
     L.jaicov_neq_get_normal.argtypes = [vp, _pd, C.c_size_t, _pd, C.c_size_t]
@@ -135,7 +136,7 @@ class Engine:
 
     def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0,
                  reduced_reference_quirk: bool = False, deterministic: bool = False, refinement: int = 0,
-                 ordinary_group_elimination: int = 0, dispersion_refinement: int = 0):
+                 ordinary_group_elimination: int = 0, dispersion_refinement: int = 0, expansion_exchange: bool = False):
         self.L = load_library()
         self.fp = fp
         self.U = fp.n_unknowns
@@ -150,6 +151,8 @@ class Engine:
         opts.deterministic = int(deterministic)
         opts.ordinary_group_elimination = int(ordinary_group_elimination)   # < 0: ordinary image groups stay outside the EO pre-elimination
         opts.dispersion_refinement = int(dispersion_refinement)             # < 0: inv(D) as the blocked Cholesky leaves it
+        opts.expansion_exchange = int(expansion_exchange)                   # sharded engines: the caller all-reduces expansion_buffer()
+        self.expansion_exchange = bool(expansion_exchange)
         opts.refinement = int(refinement)      # 0 = default (one step of iterative refinement per solve), < 0 = none, k = k steps
         self._h = C.c_void_p()
         rc = self.L.jaicov_neq_create(C.byref(self._desc), C.byref(opts), C.byref(self._h))
@@ -224,6 +227,12 @@ class Engine:
         self._chk(self.L.jaicov_neq_eo_step_buffer(self._h, C.byref(ptr), C.byref(cnt)))
         return ptr.value, cnt.value
 
+    def expansion_buffer(self):
+        """(device pointer, count) of [F | L_E^-1] for a sharded FULL_EXPANDED final pass: sum over the ranks, then solve."""
+        ptr = C.c_void_p(); cnt = C.c_size_t()
+        self._chk(self.L.jaicov_neq_expansion_buffer(self._h, C.byref(ptr), C.byref(cnt)))
+        return ptr.value, cnt.value
+
     def solve(self, invert=False):
         dx = np.zeros(max(self.U, 1))
         self._chk(self.L.jaicov_neq_solve(self._h, int(invert), _p(dx)))
@@ -296,11 +305,11 @@ class Engine:
         self._chk(self.L.jaicov_neq_set_profiling(self._h, int(on)))
 
     def kernel_stats(self, reset=False):
-        st = np.zeros(11)
-        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 11, int(reset)))
+        st = np.zeros(12)
+        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 12, int(reset)))
         return {"launches": st[0], "ms": st[1], "flops": st[2], "dense_passes": st[3], "dense_gemm_ms": st[4], "dense_flops": st[5],
                 "flow_retries": int(st[6]), "flow_stale_events": int(st[7]), "flow_stale_confirmed": int(st[8]),
-                "flow_rescued": int(st[9]), "last_refinement_correction": float(st[10])}
+                "flow_rescued": int(st[9]), "last_refinement_correction": float(st[10]), "refine_steps": int(st[11])}
 
     def cancel(self):
         """``BundleAdjustment.interrupt()`` (BundleAdjustment.java:1455): the running / next ``estimate`` ends with state -1."""

@@ -162,13 +162,13 @@ typedef struct jaicov_engine_options {
                                       point x point gather add their images' terms in arrival order (LDS fp64 atomics): ~1e-16 relative
                                       differences in N from run to run, which cond(N) ~ 1e9 turns into ~1e-9 in Qxx on the smallest
                                       test scenes.  Costs 0.7 ms per pass at config 4 (assembly 2.8 -> 3.5 ms: the waves then add in turn,
-                                      a workgroup barrier after every turn; round 2's form cost 1.7 ms).  JAICOV_DETERMINISTIC=0/1 overrides. */
+                                      a workgroup barrier after every turn; round 2's form cost 1.7 ms).  */
     int32_t  refinement;           /* iterative refinement of the step in jaicov_neq_solve: 0 = default (ONE step), < 0 = none, k > 0 = k steps
                                       (at most 4).  A step computes the residual n - N dx (and the datum border's) of the unscaled system
                                       in two-fold precision on the device and solves for the correction with the factor at hand (one forward
                                       and one backward substitution, csrc/refine.hip): the error of dx against the exact solution of the
                                       assembled system falls from cond * eps (2.6e-8 at config 4, where the reference's dspsv, MX:338-353, is
-                                      at 3.6e-9) to ~1e-12.  Costs ~1 ms per pass at config 4.  JAICOV_REFINE=k overrides.                  */
+                                      at 3.6e-9) to ~1e-12.  Costs ~1 ms per pass at config 4.                  */
     int32_t  ordinary_group_elimination; /* 0 = default: when the whole problem qualifies (every image has >= 3 observations, at most 2048 per
                                       image without a dispersion of its own, the exterior orientations own the trailing columns and are
                                       not directly observed) the exterior orientations of images whose points are ORDINARY ImageCoordinate
@@ -181,7 +181,11 @@ typedef struct jaicov_engine_options {
                                       forward error of inv(D) falls from cond(D) * eps (3e-11 at config 4, the reference's dpptrf + dpptri the
                                       same) to ~1e-14, and with it the error of N = A' inv(D) A against the exactly assembled system.  Four
                                       more GEMMs per matrix (+80 ms of engine creation at config 4).  < 0: off.                              */
-    int32_t  reserved[3];
+    int32_t  expansion_exchange;   /* != 0 on a SHARDED engine (image_begin/image_end): the caller promises to sum
+                                      jaicov_neq_expansion_buffer() over the ranks between accumulate and the inverting solve, so that
+                                      MatrixInversion.FULL is expanded from the reduced inverse on a shard too (JAICOV_INVERT_FULL_EXPANDED;
+                                      without the promise a shard falls back to the literal order-U route).  Ignored on an unsharded engine. */
+    int32_t  reserved[2];
 } jaicov_engine_options;
 
 typedef struct jaicov_engine jaicov_engine;
@@ -263,6 +267,12 @@ int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out);
  * other ranks.  dx_out[reduced_order + i] of the solve holds the same numbers.  A multi-GPU host sums the array over the ranks in
  * place (ncclAllReduce) and copies it into the tail of dx, instead of sending the host copy back to the device for the collective. */
 int jaicov_neq_eo_step_buffer(jaicov_engine *e, void **device_ptr, size_t *count);
+/* Sharded final pass with JAICOV_INVERT_FULL_EXPANDED (BA:268-271 on several GPUs): after jaicov_neq_accumulate of a pass announced
+ * with jaicov_neq_prepare_inverse(e, JAICOV_INVERT_FULL_EXPANDED), the DEVICE array [F | L_E^-1] -- F = N_EE^-1 N_ER, one 6-row band
+ * per image, dense [6 images padded to 128][reduced order padded to 128], then 36 doubles per image -- with this engine's images'
+ * entries set and zeros elsewhere.  The caller sums it over the ranks in place (one all-reduce, 371 MB at config 4) before
+ * jaicov_neq_solve(e, JAICOV_INVERT_FULL_EXPANDED, ...).  Needs engine option expansion_exchange on a shard.                     */
+int jaicov_neq_expansion_buffer(jaicov_engine *e, void **device_ptr, size_t *count);
 
 /* replaces BA.getOmega(dx) (BA:472-491): sum over groups of (w - A dx)' P (w - A dx) at the CURRENT
  * (pre-update) parameters.                                                                               */
@@ -331,7 +341,8 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
  * abandoned on the device (a bounded wait ran out) and repeated, [7] flags that only the slow-path poll found, [8] of those the
  * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == 0 ([7]..[9] are informational:
  * the slow-path poll also finds flags that were simply set late); bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
- * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).                                     */
+ * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).  With n >= 12: [11] the refinement steps
+ * per solve the engine runs (option `refinement` after clamping).                                                                */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 /* What jaicov_neq_create spent (ms, wall clock of the host): [0] the whole call, [1] host time inside the uploads of the dense
  * dispersions (pageable host memory -> device), [2] dispersions -> weights altogether (upload + batched inversion, DOPG:82-86).   */

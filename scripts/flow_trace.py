@@ -1,5 +1,5 @@
 """Stand-alone timing (and, for the dataflow factorisation, the per-task timeline) of DenseSolver::potrf on a synthetic SPD
-matrix: python scripts/flow_trace.py [n=15104] [reps=5] [trace=1].  JAICOV_POTRF_LEGACY=1 times the stream-scheduled one."""
+matrix: python scripts/flow_trace.py [n=15104] [reps=5] [trace=1].  JAICOV_FACTOR_FORM=streams times the stream-scheduled one."""
 import ctypes as C
 import os
 import sys
@@ -79,7 +79,7 @@ if want_trace and nt.value:
     mhz = t[:, 5] / np.maximum(t[:, 2] - t[:, 1], 1) * 100.0
     sel = upd_us > 200
     print(f"shader clock in the update phase (tasks > 200 us): mean {mhz[sel].mean():.0f} MHz p10 {np.percentile(mhz[sel], 10):.0f} p90 {np.percentile(mhz[sel], 90):.0f}")
-    if os.environ.get("JAICOV_FLOW_W", "1") == "1":
+    if True:
         ks = np.concatenate([np.full(nb + 1 - j, j) for j in range(nb)])
         mid = (ks > 40) & (ks < 80)
         fin_us = us[:, 3] - us[:, 2]

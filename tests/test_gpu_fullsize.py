@@ -87,9 +87,9 @@ def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4, monkeypatch
     d = engine.Engine(fp, assembly_mode=1)               # third path: J'WJ as dense A'(PA) on the matrix cores
     dx1_dense, v_dense = _adjust(d, fp, engine.INVERT_NONE)
     d.close()
-    monkeypatch.setenv("JAICOV_POTRF_LEGACY", "1")       # read when the solver is created
+    monkeypatch.setenv("JAICOV_FACTOR_FORM", "streams")   # read when the solver is created
     g = engine.Engine(fp)
-    monkeypatch.delenv("JAICOV_POTRF_LEGACY")
+    monkeypatch.delenv("JAICOV_FACTOR_FORM")
     dx1_streams, v_streams = _adjust(g, fp, engine.INVERT_NONE)
     g.close()
     scale = np.abs(dx1_full).max()

@@ -88,17 +88,15 @@ def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
     assert ei.value.code == 1
 
 
-@pytest.mark.parametrize("form", ["chain", "chain_second_1", "chain_second_2", "two_step", "one_kernel", "streams"])
+@pytest.mark.parametrize("form", ["chain", "two_step", "one_kernel", "streams"])
 @pytest.mark.parametrize("n", [384, 1152])
 def test_factor_tile_by_tile(n, form, monkeypatch):
     """The Cholesky factor itself, every 128 x 128 tile against LAPACK, under every form of the factorisation (the chain
     form's workgroups each own particular tiles: a solve / inverse check alone can hide which one is wrong)."""
     import ctypes as C
     monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
-    for k, v in {"chain_second_1": ("JAICOV_FLOW_SECOND", "1"), "chain_second_2": ("JAICOV_FLOW_SECOND", "2"), "two_step": ("JAICOV_FLOW_CHAIN", "0"),
-                 "one_kernel": ("JAICOV_FLOW_INLINE_DIAG", "1"), "streams": ("JAICOV_POTRF_LEGACY", "1")}.items():
-        if form == k:
-            monkeypatch.setenv(*v)
+    if form != "chain":
+        monkeypatch.setenv("JAICOV_FACTOR_FORM", form)          # dense.hip factor_form(): the non-default forms are named here
     lib = engine.load_library()
     lib.jaicov_debug_potrf_factor.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
     rng = np.random.default_rng(n)
@@ -158,17 +156,17 @@ def test_normal_equations_match_oracle(oracle_mod, name):
         eng.close()
 
 
-@pytest.mark.parametrize("switch", ["JAICOV_T_VECTOR", "JAICOV_NO_ASSEMBLY_FORK", "JAICOV_PP_MATERIALISE"])
-def test_assembly_switches_give_the_same_system(switch, monkeypatch):
-    """The alternative forms of the dense-block assembly kept behind switches (vector form of T = Dinv [A_c | w], camera-side
-    kernels in front of the gather instead of beside it, P' written out) assemble the same EO-reduced system as the default
-    and the same step (the default is held to the oracle by the tests around this one)."""
+@pytest.mark.parametrize("form", ["t_vector", "no_fork", "materialise"])
+def test_assembly_forms_give_the_same_system(form, monkeypatch):
+    """The alternative forms of the dense-block assembly (JAICOV_ASSEMBLY_FORM, assemble.hip: vector form of T = Dinv [A_c | w],
+    camera-side kernels in front of the gather instead of beside it, P' written out) assemble the same EO-reduced system as the
+    default and the same step (the default is held to the oracle by the tests around this one)."""
     fp = scene.make_scene(12, 150, 90, dist=scene.DIST_FULL, weights="block", n_control=5, control_dense=True)
     s2 = fp.sigma2apriori
     res = []
     for on in (False, True):
         if on:
-            monkeypatch.setenv(switch, "1")
+            monkeypatch.setenv("JAICOV_ASSEMBLY_FORM", form)
         eng = engine.Engine(fp)
         eng.set_parameters(fp.values)
         eng.build(s2, 0.5)
@@ -580,12 +578,8 @@ def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     against the oracle's packed Bunch-Kaufman solve, normal equations included.  At this order (29 block
     columns) the default is the dataflow factorisation in its chain form; the other cases force the
     stream-scheduled one, the dataflow form with the separate diagonal kernel and the one-kernel form."""
-    if factorisation == "streams":
-        monkeypatch.setenv("JAICOV_POTRF_LEGACY", "1")
-    if factorisation == "dataflow_two_step":
-        monkeypatch.setenv("JAICOV_FLOW_CHAIN", "0")
-    if factorisation == "dataflow_one_kernel":          # the form taken when kernels cannot overlap (counter collection)
-        monkeypatch.setenv("JAICOV_FLOW_INLINE_DIAG", "1")
+    if factorisation != "default":                      # one_kernel: the form taken when kernels cannot overlap (counter collection)
+        monkeypatch.setenv("JAICOV_FACTOR_FORM", {"streams": "streams", "dataflow_two_step": "two_step", "dataflow_one_kernel": "one_kernel"}[factorisation])
     fp = scene.config("cfg3")
     o = oracle_mod.Oracle(fp)
     s2 = fp.sigma2apriori

@@ -1,7 +1,8 @@
 """The N > 1 path end to end with two ranks on ONE GPU: two processes, each with its own engine over its image range, the
 reduce buffers summed by torch.distributed (backend gloo: device tensors staged through the host; RCCL refuses two ranks
 on one device).  Everything except the transport is what runs on 8 GPUs: partition, accumulate, reduce buffer (incl. the
-LM diagonal corrections), finalize, replicated solve, EO slice exchange, summed Omega."""
+LM diagonal corrections), finalize, replicated solve, EO slice exchange, summed Omega, and the FULL final pass expanded from the
+reduced inverse with the expansion's inputs exchanged between the ranks."""
 import os
 import sys
 
@@ -29,7 +30,7 @@ def _worker(rank, world, port, out_dir):
     from bundle_adjustment_amd import distributed, engine
     fp = _scene()
     lo, hi = distributed.partition_images(fp, world)[rank]
-    eng = engine.Engine(fp, image_range=(lo, hi), apply_shared=(rank == 0))
+    eng = engine.Engine(fp, image_range=(lo, hi), apply_shared=(rank == 0), expansion_exchange=True)
     eng.set_parameters(fp.values)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
@@ -37,6 +38,11 @@ def _worker(rank, world, port, out_dir):
     for lam in (0.0, 0.5):
         dx = distributed.sharded_step(eng, dist, dev, fp.sigma2apriori, lam)
         res += [dx, [distributed.sharded_omega(eng, dist, dev, fp.sigma2apriori, dx)]]
+    # the final pass of MatrixInversion.FULL on shards: all of Qxx expanded from the reduced inverse, the F bands and L_E^-1 of the
+    # other rank's images arriving through the second all-reduce (jaicov_neq_expansion_buffer)
+    dxf = distributed.sharded_step(eng, dist, dev, fp.sigma2apriori, 0.0, invert=engine.INVERT_FULL_EXPANDED)
+    assert eng.cofactor_order() == fp.n_unknowns and eng.reduced_order() == fp.n_unknowns - 6 * fp.n_images
+    res += [dxf, eng.get_cofactor()]
     np.save(os.path.join(out_dir, f"r{rank}.npy"), np.concatenate(res))
     eng.close()
     dist.barrier()
@@ -58,3 +64,9 @@ def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle_mod):
         np.testing.assert_allclose(r0[base:base + U], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
         omo = o.omega(fp.values, fp.sigma2apriori, dxo)
         assert abs(r0[base + U] - omo) <= 1e-9 * omo
+    dxo, Qo, _, _ = o.step(fp.values, fp.sigma2apriori, 0.0, True)          # dspsv + dsptri at full order (MX:338-366)
+    base = 2 * (U + 1)
+    np.testing.assert_allclose(r0[base:base + U], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    Q = r0[base + U:]
+    assert Q.size == Qo.size
+    np.testing.assert_allclose(Q, Qo, rtol=0, atol=1e-8 * np.abs(Qo).max())
