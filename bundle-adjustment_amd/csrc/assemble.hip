@@ -566,9 +566,9 @@ __device__ __forceinline__ void pp_spread_row(double rowvec, double sigma2, doub
     }
 }
 
+// What one partner contributes, formed before anything is added: g[b] = P'_pq A_q[:, b] (2 values per partner column b).
 template <bool FUSED>
-__device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const double (&ap)[6], const double (&up)[12], double sigma2,
-                                              double *strip, int cw, int c0, int cp0, int cp1, int cp2, int wlo, int whi) {
+__device__ __forceinline__ void pp_products(const PPData<FUSED> &d, const double (&up)[12], double sigma2, double (&g)[6]) {
     double p00 = d.P0.x, p01 = d.P0.y, p10 = d.P1.x, p11 = d.P1.y;
     if (FUSED) {
         p00 *= sigma2; p01 *= sigma2; p10 *= sigma2; p11 *= sigma2;
@@ -582,14 +582,28 @@ __device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const doub
     }
 #pragma unroll
     for (int b = 0; b < 3; b++) {
-        const int cq = d.cq[b];
+        g[2 * b] = p00 * d.aq[2 * b] + p01 * d.aq[2 * b + 1];
+        g[2 * b + 1] = p10 * d.aq[2 * b] + p11 * d.aq[2 * b + 1];
+    }
+}
+__device__ __forceinline__ void pp_apply(const double (&g)[6], const int (&cqs)[3], const double (&ap)[6], double *strip, int cw, int c0,
+                                         int cp0, int cp1, int cp2, int wlo, int whi) {
+#pragma unroll
+    for (int b = 0; b < 3; b++) {
+        const int cq = cqs[b];
         if (cq < c0 + wlo || cq >= c0 + whi) continue;      // [wlo, whi): the part of the strip this wave may touch
-        const double g0 = p00 * d.aq[2 * b] + p01 * d.aq[2 * b + 1];
-        const double g1 = p10 * d.aq[2 * b] + p11 * d.aq[2 * b + 1];
+        const double g0 = g[2 * b], g1 = g[2 * b + 1];
         if (cp0 >= cq) unsafeAtomicAdd(&strip[cq - c0], ap[0] * g0 + ap[1] * g1);
         if (cp1 >= cq) unsafeAtomicAdd(&strip[cw + cq - c0], ap[2] * g0 + ap[3] * g1);
         if (cp2 >= cq) unsafeAtomicAdd(&strip[2 * cw + cq - c0], ap[4] * g0 + ap[5] * g1);
     }
+}
+template <bool FUSED>
+__device__ __forceinline__ void pp_accumulate(const PPData<FUSED> &d, const double (&ap)[6], const double (&up)[12], double sigma2,
+                                              double *strip, int cw, int c0, int cp0, int cp1, int cp2, int wlo, int whi) {
+    double g[6];
+    pp_products<FUSED>(d, up, sigma2, g);
+    pp_apply(g, d.cq, ap, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
 }
 
 // everything a wave derives from its image record is the same for its 64 lanes: held in scalar registers (the compiler cannot
@@ -613,7 +627,7 @@ __device__ __forceinline__ int2 pp_range(const int2 *range, long idx) {
 template <bool FUSED, bool DET = false>
 __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             const double *__restrict__ Ubuf, double sigma2, double *__restrict__ N) {
-    extern __shared__ double strip[];              // 3 rows x cw columns
+    extern __shared__ double strip[];              // 3 rows x cw columns, + one word (DET: the turn, see below)
     constexpr int NW = PP_NT / 64;
     const int tid = threadIdx.x, lane = tid & 63, nch = pp.n_chunks, cw = pp.cw;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -640,6 +654,8 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     const int ob = pp.pt_ip_begin[pt], oe = pp.pt_ip_begin[pt + 1];
     if (rmax < c0 || (ob == oe && !(pp.plain && rmax <= pp.cmax))) return;   // plain mode: an unobserved point stores zeros
     const int2 *range = reinterpret_cast<const int2 *>(pp.range);
+    int *det_turn = reinterpret_cast<int *>(strip + 3 * cw);
+    if (DET && tid == 0) *det_turn = 0;
     for (int i = tid; i < 3 * cw; i += PP_NT) strip[i] = 0.0;
     __syncthreads();
     // Wave w takes every NW-th image of the point, with the partner ranges of the whole chunk.
@@ -683,19 +699,19 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
         }
     }
     } else {
-        // DETERMINISTIC form: the same distribution of the images over the waves and the same prefetching, but the waves ADD in
-        // turn -- round r: wave 0 adds image 4r, then wave 1 image 4r + 1, ... with a workgroup barrier after every turn -- so
-        // every entry of the strip is summed in image order whatever the timing.  The loads of all four waves still overlap; what
-        // the barriers cost is the waves' freedom to run ahead of each other.  (Round 2's form gave every wave a quarter of the
-        // strip's columns and let it walk ALL images: four times the records, row fetches and range look-ups at a quarter of the
-        // lanes: +1.7 ms per pass at config 4.  Both forms sum in image order: identical bits.)
-        const int rounds = (oe - ob + NW - 1) / NW;       // the same for every wave: the barriers below are reached by all
-        if (rounds > 0) {
+        // DETERMINISTIC form: the same distribution of the images over the waves and the same prefetching, but the ADDS into the strip
+        // happen in image order: a wave forms the products of its image (pp_products: everything up to the 18 multiplications by
+        // A_p) while earlier images are still being added, then waits for its turn -- a sequence word in LDS that says how many
+        // images of this point have been added -- issues its LDS adds, drains them (s_waitcnt lgkmcnt(0): no vmcnt, the prefetched
+        // operands of the next image stay in flight) and passes the turn on.  Every entry of the strip is summed in image order
+        // whatever the timing; only the adds themselves are serialised inside a workgroup.  (Round 3's form let the waves add in
+        // turn with a workgroup barrier after every turn -- the products were formed INSIDE the turn and every wave waited at four
+        // barriers per round: +0.7 ms per pass at config 4; round 2's walked all images with every wave: +1.7 ms.  All three sum in
+        // image order: identical bits.)
+        if (ob + wave < oe) {
             const int o0 = ob + wave;
-            const int oc0 = min(o0, oe - 1);
-            PPRecord r1 = pp_record(pp.recs, oc0);
-            int2 g1 = pp_range(rng, (long)oc0 * nrc + rci);
-            if (o0 >= oe) g1.y = g1.x;
+            PPRecord r1 = pp_record(pp.recs, o0);
+            int2 g1 = pp_range(rng, (long)o0 * nrc + rci);
             const int o1 = min(o0 + STEP, oe - 1);
             PPRecord r2 = pp_record(pp.recs, o1);
             int2 g2 = pp_range(rng, (long)o1 * nrc + rci);
@@ -703,8 +719,7 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
             double apc[6], upc[12];
             pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y, pp.ug);
             pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
-            int o = o0;
-            for (int rd = 0; rd < rounds; rd++, o += STEP) {
+            for (int o = o0; o < oe; o += STEP) {
                 const int o2 = min(o + 2 * STEP, oe - 1);
                 const PPRecord r3 = pp_record(pp.recs, o2);
                 const int2 g3 = pp_range(rng, (long)o2 * nrc + rci);
@@ -713,16 +728,19 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
                     pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y, pp.ug);
                     rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
                 }
-                for (int turn = 0; turn < NW; turn++) {
-                    if (turn == wave && o < oe) {
-                        pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
-                        for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
-                            pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y, pp.ug);
-                            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
-                        }
-                    }
-                    __syncthreads();
+                double gq[6];
+                int cqs[3] = {cur.cq[0], cur.cq[1], cur.cq[2]};
+                pp_products<FUSED>(cur, upc, sigma2, gq);
+                // my turn: o - ob images have been added
+                while (__hip_atomic_load(det_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != o - ob) __builtin_amdgcn_s_sleep(0);
+                asm volatile("" ::: "memory");
+                pp_apply(gq, cqs, apc, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
+                for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {      // ranges longer than a wave: inside the turn
+                    pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y, pp.ug);
+                    pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's adds have been performed (LDS executes a wave's operations in order)
+                if (lane == 0) __hip_atomic_store(det_turn, o - ob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 cur = nxt;
                 pp_spread_row<FUSED>(rown, sigma2, apc, upc);
                 r1 = r2; g1 = g2; r2 = r3; g2 = g3;
@@ -1000,7 +1018,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     if (pp.pt_ip_begin) {
         const dim3 gg = pp.xcd_map ? dim3((unsigned)(8 * p.n_points * ((pp.n_chunks + 7) / 8))) : dim3(p.n_points, pp.n_chunks);
         const dim3 gb(PP_NT);
-        const size_t lds = (size_t)3 * pp.cw * sizeof(double);
+        const size_t lds = (size_t)3 * pp.cw * sizeof(double) + sizeof(double);      // + the DET form's turn word
         const bool det = pp.det != 0;
         if (schur && !sb.materialise) {   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
             if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);

@@ -260,7 +260,7 @@ struct jaicov_engine {
     bool solver_has_inverse = false;
     enum { ST_NEW, ST_PARAMS, ST_ACCUMULATED, ST_BUILT, ST_SOLVED } state = ST_NEW;
     bool have_Q = false, rows_valid = false, reduced = false;
-    bool deterministic = false;  // engine option / JAICOV_DETERMINISTIC: fixed summation order in the assembly of the image groups
+    bool deterministic = true;   // engine option `deterministic` (default on): fixed summation order in the assembly of the image groups
     std::atomic<int> cancel{0};  // BundleAdjustment.interrupt() (BA:1455): polled by estimate() where the reference polls (BA:240, 320)
     bool sim_built = false;      // the system at hand was built with simulation != 0: the right-hand side is zero for ALL unknowns (BA:830-831)
     double lambda_used = 0.0;
@@ -474,7 +474,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     std::vector<int32_t> pv_image, pv_point, perm_local;
     std::vector<double> pv_x, pv_y, pv_vx, pv_vy, pv_rho;
     HIPE(e, hipSetDevice(e->device));
-    e->deterministic = e->opts.deterministic != 0;
+    e->deterministic = e->opts.deterministic >= 0;      // 0 = default = ON since round 4 (costs 0.3 ms per pass at config 4); < 0: arrival-order sums
     e->refine_steps = e->opts.refinement == 0 ? 1 : (e->opts.refinement < 0 ? 0 : std::min(e->opts.refinement, 4));
     hipDeviceProp_t prop;
     HIPE(e, hipGetDeviceProperties(&prop, e->device));

@@ -135,7 +135,7 @@ class Engine:
     """One engine per adjustment (``BundleAdjustment`` is single-shot: BundleAdjustment.java:203)."""
 
     def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0,
-                 reduced_reference_quirk: bool = False, deterministic: bool = False, refinement: int = 0,
+                 reduced_reference_quirk: bool = False, deterministic=None, refinement: int = 0,
                  ordinary_group_elimination: int = 0, dispersion_refinement: int = 0, expansion_exchange: bool = False):
         self.L = load_library()
         self.fp = fp
@@ -148,7 +148,8 @@ class Engine:
         opts.apply_shared = int(apply_shared)
         opts.assembly_mode = int(assembly_mode)
         opts.reduced_reference_quirk = int(reduced_reference_quirk)
-        opts.deterministic = int(deterministic)
+        # None: the engine's default (deterministic since round 4); True / False: on / off (arrival-order atomics, 0.3 ms faster at config 4)
+        opts.deterministic = 0 if deterministic is None else (1 if deterministic else -1)
         opts.ordinary_group_elimination = int(ordinary_group_elimination)   # < 0: ordinary image groups stay outside the EO pre-elimination
         opts.dispersion_refinement = int(dispersion_refinement)             # < 0: inv(D) as the blocked Cholesky leaves it
         opts.expansion_exchange = int(expansion_exchange)                   # sharded engines: the caller all-reduces expansion_buffer()

@@ -72,11 +72,16 @@ def project(c, x0, y0, eo, xyz, r0, dist):
 
 
 def make_scene(n_images, n_points, obs_per_image, *, dist=DIST_RADIAL, weights="diag", n_control=4,
-               control_dense=False, scale_bar=False, seed=SEED, start_noise=1.0, datum_all=True, min_rays=3):
+               control_dense=False, scale_bar=False, seed=SEED, start_noise=1.0, datum_all=True, min_rays=3, layout="sphere"):
     """Builds a FlatProblem.
 
     weights: 'diag' (sigma 0.0005), '2x2' (rho ~ U(-0.5,0.5), PartialDerivativeFactory.java:313-319) or 'block'
              (one dense SPD dispersion per image, D = L L', L = diag(sigma) + 0.1 sigma N(0,1) strictly lower).
+    layout: 'sphere' (stations on a hemisphere aimed at the centroid, every image sees most of the object and keeps a RANDOM
+            subset of obs_per_image points: two points share ~10 % of their images) or 'strips' (a block flown in strips, as real
+            photogrammetric blocks are: stations 600-900 mm above the object looking down at a grid of targets in boustrophedon order, an
+            image keeps the obs_per_image visible points NEAREST to its principal point: neighbouring points share most of their images,
+            and the first-seen numbering of BA:667-782 makes neighbouring points neighbouring columns).
     n_control control points as a DirectlyObservedParameterGroup (d = 0 when >= 3 points are observed in X,Y,Z);
     control_dense gives that group a dense dispersion.  scale_bar adds one ScaleBar (free network: d = 6 with
     n_control = 0).
@@ -89,13 +94,34 @@ def make_scene(n_images, n_points, obs_per_image, *, dist=DIST_RADIAL, weights="
     need_all = obs_per_image >= P
     eo = np.zeros((I, 6))
     ip_image, ip_point, ip_x, ip_y = [], [], [], []
+    targets = None
+    if layout == "strips":
+        ns = max(1, int(round(np.sqrt(I * 0.8))))                 # strips along Z, I / ns stations each, boustrophedon
+        per = int(np.ceil(I / ns))
+        tx = -1000 + 2000 * (np.arange(ns) + 0.5) / ns
+        targets = []
+        for a in range(ns):
+            tz = -1000 + 2000 * (np.arange(per) + 0.5) / per
+            if a & 1:
+                tz = tz[::-1]
+            targets += [(tx[a] + rng.uniform(-20, 20), z + rng.uniform(-20, 20)) for z in tz]
+        targets = np.array(targets[:I])
+    elif layout != "sphere":
+        raise ValueError(layout)
     for i in range(I):
         radius = rng.uniform(1500, 2500) * (2.2 if need_all else 1.0)
+        aim = centre
+        if targets is not None:
+            # footprint at distance d: 1.25 d x 0.83 d; obs_per_image of P points uniform over 2000 x 2000 need d ~ sqrt(4e6 obs / (1.04 P))
+            radius = 1.15 * np.sqrt(4e6 * obs_per_image / (1.04 * P))
+            aim = np.array([targets[i, 0], centre[1], targets[i, 1]])
         for _attempt in range(40):
             # station on the hemisphere Y < 0 (as the example block), uniform roll
             az = rng.uniform(0, 2 * np.pi); el = rng.uniform(np.deg2rad(25), np.deg2rad(85))
-            st = centre + radius * np.array([np.cos(el) * np.cos(az), -np.sin(el), np.cos(el) * np.sin(az)])
-            r3 = (st - centre) / np.linalg.norm(st - centre)       # camera z axis points away from the scene
+            if targets is not None:
+                el = rng.uniform(np.deg2rad(65), np.deg2rad(88))
+            st = aim + radius * np.array([np.cos(el) * np.cos(az), -np.sin(el), np.cos(el) * np.sin(az)])
+            r3 = (st - aim) / np.linalg.norm(st - aim)             # camera z axis points away from the scene
             up = np.array([0.0, 0.0, 1.0]) if abs(r3[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
             r1 = np.cross(up, r3); r1 /= np.linalg.norm(r1)
             r2 = np.cross(r3, r1)
@@ -113,7 +139,11 @@ def make_scene(n_images, n_points, obs_per_image, *, dist=DIST_RADIAL, weights="
         else:
             raise RuntimeError("could not place a station seeing enough points")
         eo[i] = e
-        sel = np.sort(rng.choice(vis, size=min(obs_per_image, vis.size), replace=False))
+        if targets is None:
+            sel = np.sort(rng.choice(vis, size=min(obs_per_image, vis.size), replace=False))
+        else:                                                     # the compact patch around the principal point
+            near = np.argsort((x[vis] - X0_EX) ** 2 + (y[vis] - Y0_EX) ** 2)[:min(obs_per_image, vis.size)]
+            sel = np.sort(vis[near])
         ip_image.append(np.full(sel.size, i)); ip_point.append(sel)
         ip_x.append(x[sel]); ip_y.append(y[sel])
     ip_image = np.concatenate(ip_image); ip_point = np.concatenate(ip_point)
@@ -221,6 +251,8 @@ def config(name: str, **kw) -> FlatProblem:
         return make_scene(100, 1000, 400, dist=DIST_FULL, weights="block", n_control=15, control_dense=True, **kw)
     if name in ("cfg4", "cfg5"):   # 500 x 5000, dense dispersion per image + dense 45x45 control block
         return make_scene(500, 5000, 500, dist=DIST_FULL, weights="block", n_control=15, control_dense=True, **kw)
+    if name == "cfg4_local":   # config 4's size and stochastic model on a block flown in strips: neighbouring points share most of their images
+        return make_scene(500, 5000, 500, dist=DIST_FULL, weights="block", n_control=15, control_dense=True, layout="strips", **kw)
     if name == "tiny":      # parity-test size: oracle finishes in milliseconds
         return make_scene(6, 40, 24, dist=DIST_FULL, weights="2x2", n_control=4, **kw)
     if name == "tiny_block":

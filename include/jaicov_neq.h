@@ -157,12 +157,13 @@ typedef struct jaicov_engine_options {
                                       right-hand side scaled twice by the preconditioner, V_c^2 n_c (BA:261-267 solve only the
                                       leading numRows, BA:273 scales all of dx; BA:430, 450-461 then use these entries for Omega
                                       and the update) -- instead of the back-substituted step.  Default 0.      */
-    int32_t  deterministic;        /* != 0: the assembly of the jointly dispersed image groups sums in a fixed order (image order), so two
-                                      runs give the same bits in N and n.  The default lets the four waves of a workgroup of the
-                                      point x point gather add their images' terms in arrival order (LDS fp64 atomics): ~1e-16 relative
-                                      differences in N from run to run, which cond(N) ~ 1e9 turns into ~1e-9 in Qxx on the smallest
-                                      test scenes.  Costs 0.7 ms per pass at config 4 (assembly 2.8 -> 3.5 ms: the waves then add in turn,
-                                      a workgroup barrier after every turn; round 2's form cost 1.7 ms).  */
+    int32_t  deterministic;        /* 0 = default = ON (since round 4), < 0 = off.  ON: the assembly of the jointly dispersed image groups sums
+                                      in a fixed order (image order), so two runs give the same bits in N, n, dx and Qxx -- the reference is
+                                      bit-reproducible, and cond(N) ~ 1e9 turns run-to-run differences of 1e-16 in N into 1e-9 in Qxx on the
+                                      smallest test scenes.  The waves of a workgroup of the point x point gather form their images' products
+                                      concurrently and pass a turn word in LDS for the adds (assemble.hip); the small reductions use fixed-order
+                                      second kernels.  Costs 0.3 ms per pass at config 4 (assembly 2.74 -> 3.0 ms; round 3's form with workgroup
+                                      barriers: 0.7, round 2's: 1.7).  OFF: LDS / memory fp64 atomics in arrival order.                        */
     int32_t  refinement;           /* iterative refinement of the step in jaicov_neq_solve: 0 = default (ONE step), < 0 = none, k > 0 = k steps
                                       (at most 4).  A step computes the residual n - N dx (and the datum border's) of the unscaled system
                                       in two-fold precision on the device and solves for the correction with the factor at hand (one forward

@@ -62,7 +62,7 @@ def main():
                  "device_variances_vs_truth": float(np.abs(np.diag(Qs) / np.diag(truth) - 1).max()),
                  "oracle_variances_vs_truth": float(np.abs(np.diag(orac) / np.diag(truth) - 1).max())}
             out[f"{name}_det{det}"] = r
-            print(name, "deterministic" if det else "default", json.dumps(r), flush=True)
+            print(name, "deterministic (default)" if det else "arrival-order sums", json.dumps(r), flush=True)
         if det == 0:
             eng.prepare_inverse(engine.INVERT_FULL)
             eng.build(s2, 0.0)
