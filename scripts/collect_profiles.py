@@ -34,4 +34,12 @@ shutil.copy(os.path.join(O, f"pmc_traffic_{tag}.json"), os.path.join(P, f"{name}
 src = os.path.join(O, f"pmc_traffic_{tag}.json")
 if os.path.exists(src):
     shutil.copy(src, os.path.join(P, "pmc_traffic.json"))      # the file bench.py reads its `traffic` from
+for c in ("cfg2", "cfg3", "cfg4_local"):
+    src = os.path.join(O, f"bench_{c}_{tag}.json")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{name}_{c}_bench.json"))
+for f, dst in ((f"create_time_{tag}.log", f"{name}_create_time.log"), (f"exactN_cfg3b_{tag}.json", f"{name}_exactN_cfg3b.json"),
+               (f"exactN_cfg4_{tag}.json", f"{name}_exactN_cfg4.json")):
+    if os.path.exists(os.path.join(O, f)):
+        shutil.copy(os.path.join(O, f), os.path.join(P, dst))
 print("collected", name)
