@@ -663,88 +663,81 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     const int2 *rng = range;
     const int nrc = nch, rci = chunk;
     const int wlo = 0, whi = cw;
-    if constexpr (!DET) {
+    // One loop for both forms, over SEGMENTS of 64 partners: a wave holds the operands of the segment at hand (`cur`) and has the
+    // next one in flight (`nxt`): the next 64 partners of the same image if its range in this chunk is longer than a wave, else the
+    // first 64 of the wave's next image (with that image's row operands).  Round 3 prefetched across images only and walked the rest of
+    // a long range without prefetch -- rare on the SURVEY 8(d) scene (55 +- 7 partners per image and chunk), the rule on a block flown
+    // in strips, where the partners of a point sit in one or two chunks (cfg4_local: up to 500 per image and chunk).
+    // (Measured alternatives of round 3, all slower at config 4: loads without the else branch 3.2-3.6 ms -- the compiler then keeps old
+    // and new contents of the operand registers alive and spills --, unconditional loads from clamped indices 3.3-3.7, two operand sets
+    // used alternately instead of the copy 3.6.)
+    // DETERMINISTIC form (the default): the ADDS into the strip happen in image order.  A wave forms the products of its segment
+    // (pp_products: everything up to the 18 multiplications by A_p) while earlier images are still being added, waits for its image's
+    // turn -- a sequence word in LDS that counts the images of this point that have been added --, issues its LDS adds (all segments
+    // of the image inside the one turn), drains them (s_waitcnt lgkmcnt(0): no vmcnt, the prefetched operands stay in flight) and
+    // passes the turn on.  Every entry of the strip is summed in image order whatever the timing; only the adds themselves are
+    // serialised inside a workgroup.  (Round 3's form let the waves add in turn with a workgroup barrier after every turn, the products
+    // formed inside the turn: +0.7 ms per pass at config 4; round 2's walked all images with every wave: +1.7 ms; this one +0.3.  All
+    // three sum in image order: identical bits.)
     if (ob + wave < oe) {
-        const int o0 = ob + wave;
-        PPRecord r1 = pp_record(pp.recs, o0);
-        int2 g1 = pp_range(rng, (long)o0 * nrc + rci);
-        const int o1 = min(o0 + STEP, oe - 1);
+        int o = ob + wave;
+        PPRecord r1 = pp_record(pp.recs, o);
+        int2 g1 = pp_range(rng, (long)o * nrc + rci);
+        const int o1 = min(o + STEP, oe - 1);
         PPRecord r2 = pp_record(pp.recs, o1);
         int2 g2 = pp_range(rng, (long)o1 * nrc + rci);
-        // (Measured alternatives, all slower than this form at config 4 -- assembly stage 3.05 ms before the coalesced copy of U:
-        // loads without the else branch 3.2-3.6 (the compiler then keeps old and new contents of the operand registers alive and
-        // spills), unconditional loads from clamped indices 3.3-3.7, two operand sets used alternately instead of the copy 3.6.)
         PPData<FUSED> cur, nxt;
         double apc[6], upc[12];
-        pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y, pp.ug);
+        int js = g1.x;                      // first partner of the segment at hand
+        bool first = true;                  // ... which is the first of its image (DET: the turn has not been taken yet)
+        pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, js + lane, g1.y, pp.ug);
         pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
-        for (int o = o0; o < oe; o += STEP) {
+        for (;;) {
+            const bool more = js + 64 < g1.y;
             const int o2 = min(o + 2 * STEP, oe - 1);
             const PPRecord r3 = pp_record(pp.recs, o2);
             const int2 g3 = pp_range(rng, (long)o2 * nrc + rci);
             double rown = 0.0;
-            if (o + STEP < oe) {
-                pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y, pp.ug);
-                rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
+            const bool adv = !more && o + STEP < oe;
+            // ONE load site for `nxt` (two, one per branch, and the compiler keeps both sets of operand registers: 66 spilled VGPRs):
+            // which record and which partners is decided in scalar registers
+            PPRecord rn;
+            rn.ipb = more ? r1.ipb : r2.ipb; rn.mp = more ? r1.mp : r2.mp; rn.lp = more ? r1.lp : r2.lp; rn.pad = 0;
+            rn.poff = more ? r1.poff : r2.poff; rn.pad2 = 0;
+            const int qn = more ? js + 64 : g2.x, qe = more ? g1.y : g2.y;
+            if (more || adv) {
+                pp_load<FUSED>(nxt, p, rn, pp.ipcol, rowsA, Ubuf, qn + lane, qe, pp.ug);
+                if (adv) rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
             }
-            pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
-            // ranges longer than a wave: the remaining passes without prefetch (into the registers of `cur`, which is done)
-            for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {
-                pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y, pp.ug);
+            if constexpr (DET) {
+                double gq[6];
+                const int cqs[3] = {cur.cq[0], cur.cq[1], cur.cq[2]};
+                pp_products<FUSED>(cur, upc, sigma2, gq);
+                if (first) {                // my image's turn: o - ob images have been added
+                    while (__hip_atomic_load(det_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != o - ob) __builtin_amdgcn_s_sleep(0);
+                    asm volatile("" ::: "memory");
+                }
+                pp_apply(gq, cqs, apc, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
+                if (!more) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's adds have been performed (LDS executes a wave's operations in order)
+                    if (lane == 0) __hip_atomic_store(det_turn, o - ob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            } else {
                 pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
             }
+            if (more) {
+                js += 64;
+                cur = nxt;
+                first = false;
+                continue;
+            }
+            o += STEP;
+            if (o >= oe) break;
             cur = nxt;
             pp_spread_row<FUSED>(rown, sigma2, apc, upc);
             r1 = r2; g1 = g2; r2 = r3; g2 = g3;
-        }
-    }
-    } else {
-        // DETERMINISTIC form: the same distribution of the images over the waves and the same prefetching, but the ADDS into the strip
-        // happen in image order: a wave forms the products of its image (pp_products: everything up to the 18 multiplications by
-        // A_p) while earlier images are still being added, then waits for its turn -- a sequence word in LDS that says how many
-        // images of this point have been added -- issues its LDS adds, drains them (s_waitcnt lgkmcnt(0): no vmcnt, the prefetched
-        // operands of the next image stay in flight) and passes the turn on.  Every entry of the strip is summed in image order
-        // whatever the timing; only the adds themselves are serialised inside a workgroup.  (Round 3's form let the waves add in
-        // turn with a workgroup barrier after every turn -- the products were formed INSIDE the turn and every wave waited at four
-        // barriers per round: +0.7 ms per pass at config 4; round 2's walked all images with every wave: +1.7 ms.  All three sum in
-        // image order: identical bits.)
-        if (ob + wave < oe) {
-            const int o0 = ob + wave;
-            PPRecord r1 = pp_record(pp.recs, o0);
-            int2 g1 = pp_range(rng, (long)o0 * nrc + rci);
-            const int o1 = min(o0 + STEP, oe - 1);
-            PPRecord r2 = pp_record(pp.recs, o1);
-            int2 g2 = pp_range(rng, (long)o1 * nrc + rci);
-            PPData<FUSED> cur, nxt;
-            double apc[6], upc[12];
-            pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, g1.x + lane, g1.y, pp.ug);
-            pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
-            for (int o = o0; o < oe; o += STEP) {
-                const int o2 = min(o + 2 * STEP, oe - 1);
-                const PPRecord r3 = pp_record(pp.recs, o2);
-                const int2 g3 = pp_range(rng, (long)o2 * nrc + rci);
-                double rown = 0.0;
-                if (o + STEP < oe) {
-                    pp_load<FUSED>(nxt, p, r2, pp.ipcol, rowsA, Ubuf, g2.x + lane, g2.y, pp.ug);
-                    rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
-                }
-                double gq[6];
-                int cqs[3] = {cur.cq[0], cur.cq[1], cur.cq[2]};
-                pp_products<FUSED>(cur, upc, sigma2, gq);
-                // my turn: o - ob images have been added
-                while (__hip_atomic_load(det_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != o - ob) __builtin_amdgcn_s_sleep(0);
-                asm volatile("" ::: "memory");
-                pp_apply(gq, cqs, apc, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
-                for (int j = g1.x + 64 + lane; j < g1.y; j += 64) {      // ranges longer than a wave: inside the turn
-                    pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, j, g1.y, pp.ug);
-                    pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's adds have been performed (LDS executes a wave's operations in order)
-                if (lane == 0) __hip_atomic_store(det_turn, o - ob + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                cur = nxt;
-                pp_spread_row<FUSED>(rown, sigma2, apc, upc);
-                r1 = r2; g1 = g2; r2 = r3; g2 = g3;
-            }
+            js = g1.x;
+            first = true;
         }
     }
     __syncthreads();
