@@ -266,7 +266,8 @@ struct jaicov_engine {
     double lambda_used = 0.0;
     std::vector<double> hB;      // [d][Upad] datum rows (unscaled), host
     double timings[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    double create_ms[4] = {0, 0, 0, 0};   // jaicov_neq_create: [0] whole call, [1] host time in the dispersion uploads, [2] dispersions -> weights (wall), [3] spare
+    double create_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // jaicov_neq_create: [0] whole call, [1] host time in the dispersion uploads, [2] dispersions -> weights (wall),
+                                                      // [3] validation + tables + structure upload, [4] work buffers + full-order solver, [5] EO pre-elimination buffers + reduced solver
     hipEvent_t ev[10];
     bool pp_plain_ok = false;   // the point x point gather may store its strips (see PPGather::plain)
     hipEvent_t ev_first = nullptr, ev_all = nullptr;   // solve(): first panel's columns / whole matrix copied into the solver
@@ -683,6 +684,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     e->n_blk_ip = (int)blk_ip_list.size();
 
     // ---- upload structure --------------------------------------------------------------------------------------
+    const auto t_phase0 = std::chrono::steady_clock::now();
     DevProblem &p = e->p;
     p.U = U; p.Upad = e->Upad; p.d = d; p.ld = e->Upad;
     p.n_points = D->n_points; p.n_cameras = D->n_cameras; p.n_images = D->n_images; p.n_dist = D->n_dist;
@@ -814,6 +816,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
         }
     }
 
+    e->create_ms[3] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_phase0).count();
     // ---- dense dispersions -> D^-1 on the device (DOPG:82-86: dpptrf + dpptri once, cached) -----------------------
     {
         double *d_w = nullptr;
@@ -863,6 +866,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     }
 
     // ---- work buffers ------------------------------------------------------------------------------------------
+    const auto t_phase1 = std::chrono::steady_clock::now();
     const size_t sq = (size_t)e->Upad * e->Upad;
     if ((rc = dalloc(e, (size_t)e->n_slots, &e->d_vals))) return rc;
     if ((rc = dalloc(e, (size_t)2 * KROW * std::max(1, D->n_image_points), &e->d_rowsA, true))) return rc;
@@ -883,6 +887,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     if ((rc = dalloc(e, (size_t)1, &e->d_omega, true))) return rc;
     if ((rc = dalloc(e, (size_t)std::max(1, e->n_blk_list) * 16 * KC_MAX * (KC_MAX + 1), &e->d_cc_partial))) return rc;
     HIPE(e, e->solver.init(e->stream, e->Upad, false, true));
+    e->create_ms[4] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_phase1).count();
+    const auto t_phase2 = std::chrono::steady_clock::now();
     // ---- EO pre-elimination is possible when every image point sits in an image block, the EO columns are the
     //      trailing columns e0 + 6*image + k, and no directly observed parameter is an EO parameter ------------------
     {
@@ -930,6 +936,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             e->solverS_ready = true;
         }
     }
+    e->create_ms[5] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_phase2).count();
     e->h_vals.assign(e->n_slots, 0.0);
     e->h_V.assign(e->Upad, 1.0);
     e->hB.assign((size_t)8 * e->Upad, 0.0);
@@ -1799,7 +1806,7 @@ extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t 
 
 extern "C" int jaicov_neq_create_timings(jaicov_engine *e, double *ms, int32_t n) {
     if (!e || !ms) return JAICOV_ERR_BAD_ARGUMENT;
-    for (int i = 0; i < n && i < 4; i++) ms[i] = e->create_ms[i];
+    for (int i = 0; i < n && i < 8; i++) ms[i] = e->create_ms[i];
     return JAICOV_OK;
 }
 

@@ -291,9 +291,10 @@ class Engine:
 
     def create_timings(self):
         """What jaicov_neq_create spent, ms of host wall clock."""
-        ms = np.zeros(4)
-        self._chk(self.L.jaicov_neq_create_timings(self._h, _p(ms), 4))
-        return {"create_ms": float(ms[0]), "dispersion_upload_host_ms": float(ms[1]), "dispersions_to_weights_ms": float(ms[2])}
+        ms = np.zeros(8)
+        self._chk(self.L.jaicov_neq_create_timings(self._h, _p(ms), 8))
+        return {"create_ms": float(ms[0]), "dispersion_upload_host_ms": float(ms[1]), "dispersions_to_weights_ms": float(ms[2]),
+                "tables_and_structure_upload_ms": float(ms[3]), "work_buffers_and_solver_ms": float(ms[4]), "elimination_buffers_and_reduced_solver_ms": float(ms[5])}
 
     def get_block_weight(self, block):
         """inv(D) of image block `block` as cached at create (DOPG:82-86 caches sigma0^2 times it), caller's observation order."""

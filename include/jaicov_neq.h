@@ -346,7 +346,9 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
  * per solve the engine runs (option `refinement` after clamping).                                                                */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 /* What jaicov_neq_create spent (ms, wall clock of the host): [0] the whole call, [1] host time inside the uploads of the dense
- * dispersions (pageable host memory -> device), [2] dispersions -> weights altogether (upload + batched inversion, DOPG:82-86).   */
+ * dispersions (pageable host memory -> device), [2] dispersions -> weights altogether (upload + batched inversion, DOPG:82-86),
+ * [3] validation, tables and structure upload, [4] work buffers + the full-order solver, [5] EO pre-elimination buffers + the
+ * reduced solver.                                                                                                              */
 int jaicov_neq_create_timings(jaicov_engine *e, double *ms, int32_t n);
 /* Parity hook for DOPG:82-86 / MX:304-324: inv(D) of image block `block` as the engine caches it (the reference caches
  * sigma0^2 times it), row-major m x m with m = 2 * (points of the block), rows and columns in the caller's observation order;

@@ -153,3 +153,70 @@ def test_not_positive_definite_dispersion_is_reported():
     with pytest.raises(engine.EngineError) as ei:
         engine.Engine(fp)
     assert ei.value.code == 1                                             # JAICOV_ERR_SINGULAR: MatrixNotSPDException (DOPG:85-86)
+
+
+def test_ordinary_images_sharded(oracle_mod):
+    """Two engines over disjoint image ranges of a scene WITHOUT joint dispersions: both take the elimination (the decision is made on
+    the whole problem), their reduced systems add up to the single engine's, each back-substitutes its own images' EO step."""
+    fp = scene.config("tiny")
+    s2 = fp.sigma2apriori
+    dxo, _, _, _ = oracle_mod.Oracle(fp).step(fp.values, s2, 0.0, False)
+    full = engine.Engine(fp); full.set_parameters(fp.values); full.build(s2); N, n = full.get_normal()
+    e0 = full.reduced_order()
+    assert e0 == fp.n_unknowns - 6 * fp.n_images
+    a = engine.Engine(fp, image_range=(0, 2), apply_shared=True)
+    b = engine.Engine(fp, image_range=(2, fp.n_images), apply_shared=False)
+    for e_ in (a, b):
+        e_.set_parameters(fp.values); e_.accumulate(s2)
+        assert e_.reduced_order() == e0
+    Na, na = a.get_normal(); Nb, nb = b.get_normal()
+    np.testing.assert_allclose(Na + Nb, N, rtol=1e-11, atol=1e-12 * np.abs(N).max())
+    np.testing.assert_allclose(na + nb, n, rtol=1e-11, atol=1e-12 * np.abs(n).max())
+    np.testing.assert_allclose(full.solve(False), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    for e_ in (full, a, b):
+        e_.close()
+
+
+def test_simulation_on_ordinary_images_leaves_parameters_and_gives_the_oracles_cofactors(oracle_mod):
+    """EstimationType.SIMULATION (BA:228-236, 830-831: no right-hand side, no update, cofactors only) through the elimination of
+    ordinary image groups, REDUCED and FULL."""
+    fp = scene.config("tiny")
+    o = oracle_mod.Oracle(fp)
+    vo, Qo, ro = o.estimate(simulation=True)
+    U = fp.n_unknowns
+    Qo = packed_to_full(Qo, U)
+    for inv in (engine.INVERT_REDUCED, engine.INVERT_FULL):
+        eng = engine.Engine(fp)
+        v, r = eng.estimate(invert=inv, simulation=True)
+        assert r.state == 1
+        np.testing.assert_array_equal(v, fp.values)
+        k = eng.cofactor_order()
+        assert k == (U - 6 * fp.n_images if inv == engine.INVERT_REDUCED else U)
+        Q = packed_to_full(eng.get_cofactor(), k)
+        np.testing.assert_allclose(Q, Qo[:k, :k], rtol=0, atol=1e-8 * np.abs(Qo).max())
+        eng.close()
+
+
+def test_two_cameras_with_ordinary_images(oracle_mod):
+    """The elimination of ordinary (2 x 2 weighted) image groups with two cameras of different distortion sets: N, n, the step and the
+    variances against the oracle (test_gpu_edge_cases.check_against_oracle)."""
+    from bundle_adjustment_amd.problem import DIST_RADIAL_AI
+    import test_gpu_edge_cases as ec
+    base = scene.make_scene(8, 60, 36, dist=scene.DIST_FULL, weights="2x2", n_control=5)
+    P, I = base.n_points, base.n_images
+    nd = base.dist_kind.size
+    keep = (base.dist_kind <= 1) | (base.dist_kind == DIST_RADIAL_AI)
+    nd1 = int(keep.sum())
+    s_io = 3 * P
+    v = base.values
+    values = np.concatenate([v[:s_io], v[s_io:s_io + 3], v[s_io:s_io + 3], v[s_io + 3:s_io + 3 + nd],
+                             v[s_io + 3:s_io + 3 + nd][keep], v[s_io + 3 + nd:]])
+    image_camera = np.array([0] * (I // 2) + [1] * (I - I // 2), np.int32)
+    two = ec.renumber(base, image_camera=image_camera, cam_dist_begin=np.array([0, nd, nd + nd1], np.int32),
+                      cam_r0=np.array([base.cam_r0[0], base.cam_r0[0]]),
+                      dist_kind=np.concatenate([base.dist_kind, base.dist_kind[keep]]).astype(np.int32),
+                      dist_order=np.concatenate([base.dist_order, base.dist_order[keep]]).astype(np.int32),
+                      values=values, truth=None)
+    assert two.n_image_blocks == 0
+    reduced = ec.check_against_oracle(oracle_mod, two)
+    assert reduced
