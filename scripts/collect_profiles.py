@@ -27,7 +27,7 @@ for kind in ("fetch", "write"):
         w = csv.writer(fh)
         w.writerow(["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Counter_Name", "Counter_Value"])
         for r in rows:
-            if any(k in r["Kernel_Name"] for k in KEEP) and not ("chol_tile_kernel" in r["Kernel_Name"] and float(r["Counter_Value"]) < lim):
+            if any(k in r["Kernel_Name"] for k in KEEP) and "slice_rows_kernel" not in r["Kernel_Name"] and not ("chol_tile_kernel" in r["Kernel_Name"] and float(r["Counter_Value"]) < lim):
                 w.writerow([r["Dispatch_Id"], r["Kernel_Name"][:90], r["Grid_Size"], r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"],
                             r["Counter_Name"], r["Counter_Value"]])
 shutil.copy(os.path.join(O, f"pmc_traffic_{tag}.json"), os.path.join(P, f"{name}_pmc", "pmc_traffic.json")) if os.path.exists(os.path.join(O, f"pmc_traffic_{tag}.json")) else None

@@ -24,7 +24,7 @@ def dispatches(d, counter):
             continue
         name = r["Kernel_Name"]
         for k in [DOMINANT] + ASSEMBLY:
-            if k in name:
+            if k in name and not (k == "rows_kernel" and "slice_rows_kernel" in name):      # batchinv.hip's slicing kernel is not the Jacobian-rows kernel
                 out.setdefault(k, []).append(float(r["Counter_Value"]))
     return out
 
