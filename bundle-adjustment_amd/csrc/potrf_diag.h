@@ -29,11 +29,20 @@ __device__ __forceinline__ double bcast(double v, int src_lane) {
 
 // 16x16 Cholesky + inverse of the diagonal block at (c0,c0) in the registers of ONE wave (lane i < 16 = row i).
 // The reciprocal square root replaces sqrt + divide on the 128-step critical path (v_rsq_f64 + Newton, ~1 ulp).
+// Round 4: the forward substitution X = L^-1 (lane c = column c of X) no longer FOLLOWS the factorisation as a second chain of 16
+// dependent steps; step j of it runs inside step j of the factorisation: it needs column j of L only -- the very values
+// L[k][j], k > j, that the right-looking update of the factor fetches (v_readlane for k = j + 1, LDS broadcast loads for the rest),
+// so the two share their loads, and its products are independent of the factor's next pivot: they fill the latency of the
+// rsqrt / Newton / readlane chain instead of waiting behind it.  (The chain workgroup of the dataflow factorisation spends 41 of its
+// 70 us per block column here: at orders where the chain binds -- config 3, the first and last block columns of config 4 -- this
+// kernel's time is the factorisation's.)
 __device__ __forceinline__ void chol16_inv(double *S, double *Wd_p, int c0, int lane, int *info, int blk) {
     const int l15 = lane & 15;
-    double a[16], x[16], rinv[16];
+    double a[16], x[16], sres[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) a[k] = S[(c0 + l15) * DP + c0 + k];
+#pragma unroll
+    for (int i = 0; i < 16; i++) sres[i] = (l15 == i) ? 1.0 : 0.0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         double d = bcast(a[j], j);
@@ -44,27 +53,22 @@ __device__ __forceinline__ void chol16_inv(double *S, double *Wd_p, int c0, int 
         double rl = rsqrt(d);
         rl = rl * (1.5 - 0.5 * d * rl * rl);         // one more Newton step: full fp64 accuracy
         const double ljj = d * rl;
-        rinv[j] = rl;
         a[j] = (l15 == j) ? ljj : a[j] * rl;
+        x[j] = sres[j] * rl;                         // row j of X = L^-1 (lane c: column c)
         // column j of L goes to LDS; the next column, which the following step waits for, gets its multiplier by
         // v_readlane (short latency), the other 14-j columns read theirs back from LDS as broadcast loads (pipelined)
         if (lane < 16 && lane >= j) S[(c0 + lane) * DP + c0 + j] = a[j];
-        if (j + 1 < 16) a[j + 1] -= a[j] * bcast(a[j], j + 1);
+        if (j + 1 < 16) {
+            const double l1 = bcast(a[j], j + 1);    // L[j+1][j]
+            a[j + 1] -= a[j] * l1;
+            sres[j + 1] -= l1 * x[j];
+        }
 #pragma unroll
-        for (int k = j + 2; k < 16; k++) a[k] -= a[j] * S[(c0 + k) * DP + c0 + j];
-    }
-    // the factor is in LDS now: the inverse below reads L[i][k] from there as wave-uniform (broadcast) loads, which the
-    // hardware pipelines, instead of 120 v_readlane pairs on the scalar path
-    // X = L^-1 by forward substitution, lane c holds column c; column-oriented so that the 15-k updates that follow
-    // x[k] are independent of each other (the dependent chain is 16 links, not 120)
-    double sres[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) sres[i] = (l15 == i) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        x[k] = sres[k] * rinv[k];
-#pragma unroll
-        for (int i = k + 1; i < 16; i++) sres[i] -= S[(c0 + i) * DP + c0 + k] * x[k];
+        for (int k = j + 2; k < 16; k++) {
+            const double lk = S[(c0 + k) * DP + c0 + j];      // L[k][j], the same for every lane
+            a[k] -= a[j] * lk;
+            sres[k] -= lk * x[j];
+        }
     }
     if (lane < 16) {
 #pragma unroll
@@ -113,41 +117,56 @@ __device__ __forceinline__ void diag_load(const double *A, long ld, double *S, c
     __syncthreads();
 }
 
+// panel-solve tile: S[R][p] <- S[R][p] * Wdd[p]'  (L21 = A21 inv(L11)' with the inverted 16x16 diagonal block)
+__device__ __forceinline__ void diag_solve_tile(double *S, const double *Wd, int R, int p, int l15, int l4) {
+    const int c0 = 16 * p;
+    d4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        const double av = S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
+        const double bv = Wd[p * 16 * WDP + l15 * WDP + 4 * ks + l4];   // B[k][j] = Wdd[j][k]
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + c0 + l15] = acc[r];
+}
+
 // diag_factor: S (lower part) <- L in place, Wd <- inverses of the eight 16x16 diagonal blocks of L.
+// Per 16-column panel p the critical path is: row tile (p+1, p) of the panel solve -> the next diagonal block (p+1, p+1) minus its
+// square -> Cholesky + inverse of that block.  Round 4: wave 0 walks that path ALONE, tile by tile through LDS (a wave's LDS operations
+// execute in order: no workgroup barrier between its steps), while waves 1-3 solve the other row tiles of the panel; one barrier; then
+// wave 0 factors the diagonal block while waves 1-3 update everything else behind the panel (block column p+1 below the diagonal and
+// the trailing tiles); one barrier.  Two barriers per panel where round 1's form had three, and the diagonal block's update no longer
+// waits for the whole block column.  (potrf in the chain workgroup: 41 -> 28 us with the fused 16x16 factor / inverse, -> see DESIGN.md.)
 __device__ __forceinline__ void diag_factor(double *S, double *Wd, int *info, int blk, int dbg, const int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
     if (wave == 0 && !(dbg & 1)) chol16_inv(S, Wd, 0, lane, info, blk);
     __syncthreads();
-    for (int p = 0; p < 8; p++) {
+    for (int p = 0; p < 7; p++) {
         if (dbg & 2) break;
         const int c0 = 16 * p;
-        // ---- panel solve: L21 = A21 * Wdd' for the row tiles below ------------------------------------------
-        for (int R = p + 1 + wave; R < 8; R += 4) {
-            d4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const double av = S[(16 * R + l15) * DP + c0 + 4 * ks + l4];
-                const double bv = Wd[p * 16 * WDP + l15 * WDP + 4 * ks + l4];   // B[k][j] = Wdd[j][k]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) S[(16 * R + l4 + 4 * r) * DP + c0 + l15] = acc[r];
+        if (wave == 0) {
+            diag_solve_tile(S, Wd, p + 1, p, l15, l4);                  // L[p+1][p]
+            diag_update_tile(S, p + 1, p + 1, c0, l15, l4);            // (p+1, p+1) -= L[p+1][p] L[p+1][p]'
+        } else {
+            for (int R = p + 1 + wave; R < 8; R += 3) diag_solve_tile(S, Wd, R, p, l15, l4);     // L[R][p], R >= p + 2
         }
         __syncthreads();
-        if (p == 7) break;
-        // ---- phase A: block column p+1 of the trailing update (the next diagonal block and its panel) ----------
-        for (int R = p + 1 + wave; R < 8; R += 4) diag_update_tile(S, R, p + 1, c0, l15, l4);
-        __syncthreads();
-        // ---- phase B: wave 0 factors the next diagonal block while waves 1-3 finish the trailing update ----
         if (wave == 0) {
             if (!(dbg & 1)) chol16_inv(S, Wd + (p + 1) * 16 * WDP, 16 * (p + 1), lane, info, blk);
         } else {
-            const int rem = 6 - p, nt = rem * (rem + 1) / 2;     // tiles (R,Q), p+2 <= Q <= R <= 7
+            // block column p+1 below the diagonal, then the trailing tiles (R, Q), p + 2 <= Q <= R <= 7: nt tiles in all
+            const int rem = 6 - p, nc = rem, nt = nc + rem * (rem + 1) / 2;
             for (int t = wave - 1; t < nt; t += 3) {
-                int rr = 0;
-                while ((rr + 1) * (rr + 2) / 2 <= t) ++rr;
-                diag_update_tile(S, p + 2 + rr, p + 2 + (t - rr * (rr + 1) / 2), c0, l15, l4);
+                if (t < nc) {
+                    diag_update_tile(S, p + 2 + t, p + 1, c0, l15, l4);
+                } else {
+                    const int u = t - nc;
+                    int rr = 0;
+                    while ((rr + 1) * (rr + 2) / 2 <= u) ++rr;
+                    diag_update_tile(S, p + 2 + rr, p + 2 + (u - rr * (rr + 1) / 2), c0, l15, l4);
+                }
             }
         }
         __syncthreads();
