@@ -96,6 +96,8 @@ struct FlowArgs {
     int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
     int crit_prio;           // s_setprio level of the tasks on the critical chain; 0 = none
     int keep;                // chain form: blocks >= keep on an XCD that hosts a chain workgroup leave at once (0: none do)
+    int second_wg;           // chain form: there is a third chain workgroup
+    int second_update;       // chain form: workgroup 2 also subtracts its tile from tile (c+2, c+1)
     int inv_wt;              // chain form: the inverses leave write-through (1) or plainly behind a release (0)
     int crit_span;           // ... which are the tiles (i, j) with i <= j + crit_span
     int *wgstate;            // [grid] where each workgroup is: ticket << 12 | k << 4 | stage (flow_report_stall reads it after a stall)
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
     // (16 000 factorisations without a stall since; 7-8 expected at the earlier rate).
     if (!INLINE_DIAG && g.keep > 0 && (int)blockIdx.x >= g.keep) {
         const int xcc = 1 + (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
-        if (xcc == flow_ld(g.ctrl + 9) || xcc == flow_ld(g.ctrl + 11)) return;
+        if (xcc == flow_ld(g.ctrl + 9) || xcc == flow_ld(g.ctrl + 11) || (g.second_wg && xcc == flow_ld(g.ctrl + 13))) return;
     }
     for (;;) {
         if (tid == 0) s_msg[0] = atomicAdd(g.ctrl + FLOW_TICKET, 1);
@@ -759,6 +761,75 @@ __device__ __forceinline__ void chain_role_inverses(const FlowArgs *gp, double *
     }
     return;
 }
+__device__ __forceinline__ void chain_role_second(const FlowArgs *gp, double *S, double *Wd, int *s_okp) {
+    const FlowArgs &g = *gp;
+    const int tid = threadIdx.x;
+    // ---- the second subdiagonal: workgroup 2 finishes tile (c+2, c) by the same block forward substitution as the chain
+    //      (from L_cc itself: it does not wait for the inverse) and subtracts it from tile (c+2, c+1), the tile the chain
+    //      workgroup needs next -- the path that used to take three tile workgroups in a row (inverse -> product with
+    //      the inverse -> update) and set the period of the chain.
+    for (int c = 0; c + 2 < g.nb; c++) {
+        if (tid == 0) {
+            const bool r = flow_spin(g.factored + c, 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();
+        if ((*s_okp) == 0) return;
+        __syncthreads();
+        d4_t y[8][2];
+        {
+            FLOW_OPAQUE_TID(tq);
+            diag_load(g.L + (long)c * 128 * g.ld + (long)c * 128, g.ld, S, tq);
+            diag_block_inverses(S, Wd, tq);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c, c + 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();       // also: Wd is complete
+        if ((*s_okp) == 0) return;
+        __syncthreads();
+        double *T2 = g.L + (long)(c + 2) * 128 * g.ld + (long)c * 128;      // tile (c+2, c)
+        {
+            FLOW_OPAQUE_TID(tq);
+            chain_tile_load(T2, g.ld, y, tq);
+            chain_tile_solve(y, S, Wd, tq);
+            chain_tile_store(T2, g.ld, y, tq);
+        }
+        drain_stores();
+        __syncthreads();       // L[c+2][c] has landed; every wave has read L_cc for the last time
+        if (tid == 64) flow_st(g.done + (long)(c + 2) * g.fs + c, 1);
+        if (!g.second_update) continue;
+        if (tid == 0) {
+            bool r = flow_spin(g.applied + (long)(c + 2) * g.fs + c + 1, c + 1, g.ctrl, g.timeout, nullptr);
+            r = r && flow_spin(g.done + (long)(c + 1) * g.fs + c, 1, g.ctrl, g.timeout, nullptr);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            drain_stores();
+            (*s_okp) = r ? 1 : 0;
+        }
+        __syncthreads();
+        if ((*s_okp) == 0) return;
+        __syncthreads();
+        {
+            FLOW_OPAQUE_TID(tq);
+            d4_t t[8][2];
+            chain_tile_to_lds(g.L + (long)(c + 1) * 128 * g.ld + (long)c * 128, g.ld, S, tq);      // L[c+1][c]
+            chain_tile_load(T2 + 128, g.ld, t, tq);                                                 // tile (c+2, c+1)
+            __syncthreads();
+            chain_tile_update(t, y, S, tq);
+            chain_tile_store(T2 + 128, g.ld, t, tq);
+        }
+        drain_stores();
+        __syncthreads();
+        if (tid == 64) flow_st(g.applied + (long)(c + 2) * g.fs + c + 1, c + 2);
+    }
+    return;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Chain form of the diagonal kernel: TWO workgroups, each on a reserved CU of its own.
@@ -787,6 +858,7 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
         if (g.alive) __hip_atomic_store(g.alive + blockIdx.x, g.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (blockIdx.x == 1) { chain_role_inverses(&g, S, Wd, &s_ok); return; }
+    if (blockIdx.x == 2) { chain_role_second(&g, S, Wd, &s_ok); return; }
     // ---- the chain -------------------------------------------------------------------------------------------------
     if (tid == 0) {
         const bool r = flow_spin(g.applied, 1, g.ctrl, g.timeout, nullptr);      // tile (0, 0): scaled, in L
@@ -841,15 +913,17 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
 // columns; the tiles of the group's diagonal blocks first, then row by row the w tiles of a row, which stream the same A
 // strip L[i][0..j) at the same time (the second reader finds it in L2 / the Infinity Cache).  Either way a tile only depends
 // on tiles that come earlier in the list.
-static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain) {
+static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain, int second) {
     std::vector<int4> tasks;
     tasks.reserve((size_t)nb * (row_blocks + 1) / 2 + row_blocks);
     if (w < 1) w = 1;
     // chain form (potrf_chain_kernel): the diagonal tile (j, j) is visited for the block columns < j - 1 only and the tile below
-    // it, (j + 1, j), is not finished: the chain workgroup takes both from there.
+    // it, (j + 1, j), is not finished: the chain workgroup takes both from there.  With the optional third workgroup
+    // (`second` = 1 / 2) the tile (j + 2, j) is not finished either, and (2) the tile (j + 1, j) lacks its last update.
     auto task = [&](int i, int j) {
         if (chain && i == j) return make_int4(i, j, 0, std::max(j - 1, 0));
-        if (chain && i == j + 1 && i < nb) return make_int4(i, j, 0, j);
+        if (chain && i == j + 1 && i < nb) return make_int4(i, j, 0, second >= 2 ? std::max(j - 1, 0) : j);   // second = 2: the last update comes from workgroup 2
+        if (chain && second >= 1 && i == j + 2 && i < nb) return make_int4(i, j, 0, j);     // all updates; workgroup 2 finishes it
         return make_int4(i, j, 0, j | FLOW_FIN);
     };
     for (int j0 = 0; j0 < nb; j0 += w) {
@@ -865,9 +939,9 @@ static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain
 }  // namespace jaicov
 // debug / tests (no device needed): the task list of the dataflow factorisation, 4 ints per task {i, j, k0, k1 | FIN << 20};
 // returns the number of tasks (the first `cap` are written)
-extern "C" int jaicov_debug_flow_tasks(int nb, int row_blocks, int w, int chain, int *out, int cap) {
+extern "C" int jaicov_debug_flow_tasks(int nb, int row_blocks, int w, int chain, int second, int *out, int cap) {
     if (nb < 1 || row_blocks < nb) return -1;
-    const std::vector<int4> t = jaicov::flow_schedule(nb, row_blocks, w, chain != 0);
+    const std::vector<int4> t = jaicov::flow_schedule(nb, row_blocks, w, chain != 0, second);
     for (size_t q = 0; q < t.size() && (int)q < cap; q++) {
         out[4 * q] = t[q].x; out[4 * q + 1] = t[q].y; out[4 * q + 2] = t[q].z; out[4 * q + 3] = t[q].w;
     }
@@ -916,7 +990,17 @@ hipError_t DenseSolver::flow_init() {
     // chain form unless kernels cannot run side by side (one-kernel form, diagonal blocks inline) or it is switched off
     flow_one_kernel = !flow_kernels_overlap();
     flow_chain = !flow_one_kernel && factor_form() != FACTOR_TWO_STEP;
-    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, 1, flow_chain);
+    // Third chain workgroup for the second subdiagonal: it finishes tile (c+2, c) by the chain's own forward substitution (from L_cc
+    // itself: no wait for the inverse workgroup) and subtracts it from tile (c+2, c+1), the tile the chain workgroup needs next.
+    // Rounds 2 and 3 measured it flat (22.4 +- 0.3 ms at order 15 104) and round 4's prune removed it -- for a day: once potrf of the
+    // 128-block had fallen from 41 to 27 us (potrf_diag.h) the chain workgroup's own cycle (59 us) was no longer the one that
+    // binds at small orders; the path potrf(c-1) -> inverse -> product with the inverse -> last update of tile (c+1, c) was (the chain
+    // waited 6-9 us per block column for that tile at order 3 072), and that is the path this workgroup shortens: order 3 072
+    // 1.70 -> 1.58 ms.  At order 8 192 it is neutral (5.3 vs 5.4 ms) and at 15 104 it changes nothing (22.7 vs 22.8 ms: the tiles it
+    // needs are late by the same path one diagonal further out, and the row chain of the tile kernel binds), so it is used below
+    // 48 block columns only.  JAICOV_FACTOR_FORM=chain2 / chain3 (test hooks): the chain form with two / three workgroups at any order.
+    flow_second = flow_chain && factor_form() != FACTOR_CHAIN2 && (nb < 48 || factor_form() == FACTOR_CHAIN3) ? 2 : 0;
+    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, 1, flow_chain, flow_second);
     flow_tasks = (int)tasks.size();
     flow_task_host = tasks;
     HIPCHK(hipMalloc(&flow_task_list, tasks.size() * sizeof(int4)));
@@ -993,6 +1077,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.ctrace = flow_trace ? flow_trace + 8 * (size_t)flow_tasks : nullptr;
     g.fake_a = 0;
     g.crit_prio = 1;
+    g.second_update = flow_second >= 2 ? 1 : 0;
+    g.second_wg = flow_second ? 1 : 0;
     // "the last eight workgroups of every XCD" presumes the grid the observation was made with: two workgroups per CU dealt
     // round-robin to eight XCDs.  Any other device shape keeps every workgroup: the rule would pick the wrong ones.
     {
@@ -1029,7 +1115,7 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     HIPCHK(hipEventRecord(flow_e0, stream));
     HIPCHK(hipStreamWaitEvent(dstream, flow_e0, 0));
     if (all_ready) HIPCHK(hipStreamWaitEvent(dstream, all_ready, 0));
-    if (flow_chain) hipLaunchKernelGGL(potrf_chain_kernel, dim3(2), dim3(256), 0, dstream, g);
+    if (flow_chain) hipLaunchKernelGGL(potrf_chain_kernel, dim3(flow_second ? 3 : 2), dim3(256), 0, dstream, g);
     else hipLaunchKernelGGL(potrf_diag_chain_kernel, dim3(1), dim3(256), 0, dstream, g);
     HIPCHK(hipGetLastError());
     // Residency.  The diagonal kernel needs a whole CU's LDS and runs on the stream whose CU mask holds one CU of every XCD.
@@ -1042,7 +1128,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
         const auto t0 = std::chrono::steady_clock::now();
         int spins = 0;
         while (__atomic_load_n(flow_alive, __ATOMIC_ACQUIRE) != g.seq ||
-               (flow_chain && __atomic_load_n(flow_alive + 1, __ATOMIC_ACQUIRE) != g.seq)) {
+               (flow_chain && (__atomic_load_n(flow_alive + 1, __ATOMIC_ACQUIRE) != g.seq ||
+                               (flow_second && __atomic_load_n(flow_alive + 2, __ATOMIC_ACQUIRE) != g.seq)))) {
             if ((++spins & 1023) == 0) {
                 const double waited_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
                 if (waited_s > 30.0) {
@@ -1098,9 +1185,9 @@ void DenseSolver::flow_report_stall() {
                     applied[(size_t)(c + 1) * nb + c] - 1, applied[(size_t)(c + 1) * nb + c + 1] - 1, c);
     }
     fprintf(stderr, "\n");
-    for (int b = 0; b < 2; b++) {
+    for (int b = 0; b < 3; b++) {
         const unsigned hw = (unsigned)f[8 + 2 * b];
-        if (flow_chain)
+        if (flow_chain && (b < 2 || flow_second))
             fprintf(stderr, "jaicov:   chain workgroup %d runs on [xcc %d se %u sh %u cu %u]\n", b, f[9 + 2 * b] - 1, (hw >> 13) & 7, (hw >> 12) & 1, (hw >> 8) & 0xf);
     }
     // the oldest tickets still in flight, and what their workgroups were doing (1 drawn, 2 waiting for an earlier visit / the

@@ -16,7 +16,7 @@ struct GemmArgs;
 
 constexpr int DENSE_NB = 128;      // diagonal block handled by one workgroup in LDS
 constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry at once
-enum { FACTOR_DEFAULT = 0, FACTOR_STREAMS = 1, FACTOR_TWO_STEP = 2, FACTOR_ONE_KERNEL = 3 };
+enum { FACTOR_DEFAULT = 0, FACTOR_STREAMS = 1, FACTOR_TWO_STEP = 2, FACTOR_ONE_KERNEL = 3, FACTOR_CHAIN2 = 4, FACTOR_CHAIN3 = 5 };
 int factor_form();                 // JAICOV_FACTOR_FORM (dense.hip): test hook for the non-default forms of the factorisation
 
 struct DenseSolver {
@@ -63,6 +63,7 @@ struct DenseSolver {
 
     // dataflow factorisation (cholflow.hip): the whole potrf as two concurrent launches, dependencies as flags in memory
     bool flow_ready = false, flow_timed = false, flow_chain = false, flow_one_kernel = false;
+    int flow_second = 0;                 // third chain workgroup (cholflow.hip): 0 = none, 2 = it finishes tile (c+2, c) and subtracts it from (c+2, c+1)
     int flow_wg_off = 0;                 // offset of the per-workgroup state words in flow_flags (read by the device)
     long long flow_stale_events = 0, flow_stale_confirmed = 0, flow_rescued = 0;   // flags that only the read-modify-write poll saw (fetch_info)
     std::vector<int4> flow_task_host;    // the task list (flow_report_stall)

@@ -818,7 +818,7 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double *M, long ld, int
     }
 }
 
-// JAICOV_FACTOR_FORM = streams | two_step | one_kernel: the forms of the factorisation other than the default (dataflow, chain
+// JAICOV_FACTOR_FORM = streams | two_step | one_kernel | chain2 | chain3: the forms of the factorisation other than the default (dataflow, chain
 // form), each named by a case of tests/test_gpu_parity.py (test_factor_tile_by_tile, test_config3_step_against_oracle).  Read at
 // every call: the tests switch it between engines of one process.
 int factor_form() {
@@ -827,6 +827,8 @@ int factor_form() {
     if (!strcmp(e, "streams")) return FACTOR_STREAMS;
     if (!strcmp(e, "two_step")) return FACTOR_TWO_STEP;
     if (!strcmp(e, "one_kernel")) return FACTOR_ONE_KERNEL;
+    if (!strcmp(e, "chain2")) return FACTOR_CHAIN2;          // the chain form with two chain workgroups (no third one for the second subdiagonal)
+    if (!strcmp(e, "chain3")) return FACTOR_CHAIN3;          // ... with three, whatever the order (default: below 48 block columns)
     return FACTOR_DEFAULT;
 }
 

@@ -18,13 +18,12 @@ FIN = 1 << 20
 
 
 def tasks(nb, rows, w, chain, second=0):
-    assert second == 0            # the third chain workgroup (round 2, measured flat) was removed in round 4
     lib = engine.load_library()
-    lib.jaicov_debug_flow_tasks.argtypes = [C.c_int] * 4 + [C.c_void_p, C.c_int]
-    n = lib.jaicov_debug_flow_tasks(nb, rows, w, chain, None, 0)
+    lib.jaicov_debug_flow_tasks.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int]
+    n = lib.jaicov_debug_flow_tasks(nb, rows, w, chain, second, None, 0)
     assert n > 0
     out = np.zeros((n, 4), np.int32)
-    assert lib.jaicov_debug_flow_tasks(nb, rows, w, chain, out.ctypes.data, n) == n
+    assert lib.jaicov_debug_flow_tasks(nb, rows, w, chain, second, out.ctypes.data, n) == n
     return out
 
 
@@ -108,7 +107,7 @@ class Replay:
 
 
 @pytest.mark.parametrize("nb", [1, 2, 3, 5, 29, 118])
-@pytest.mark.parametrize("form", [(0, 0), (1, 0)])
+@pytest.mark.parametrize("form", [(0, 0), (1, 0), (1, 1), (1, 2)])
 @pytest.mark.parametrize("w", [1, 4])
 def test_task_list_is_complete_and_deadlock_free(nb, form, w):
     chain, second = form

@@ -88,7 +88,7 @@ def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
     assert ei.value.code == 1
 
 
-@pytest.mark.parametrize("form", ["chain", "two_step", "one_kernel", "streams"])
+@pytest.mark.parametrize("form", ["chain", "chain2", "chain3", "two_step", "one_kernel", "streams"])
 @pytest.mark.parametrize("n", [384, 1152])
 def test_factor_tile_by_tile(n, form, monkeypatch):
     """The Cholesky factor itself, every 128 x 128 tile against LAPACK, under every form of the factorisation (the chain

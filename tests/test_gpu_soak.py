@@ -37,3 +37,29 @@ def test_no_factorisation_is_abandoned_over_many_passes(cfg4_scene):
     eng.close()
     assert st["flow_retries"] == 0, st
     # (flow_rescued / flow_stale_* are informational: a flag found by the slow-path poll, possibly after an ordinary long wait)
+
+
+def test_no_factorisation_is_abandoned_at_config3_size():
+    """The same at config 3 (order 3 014 after the elimination of the ordinary images' EO: 24 block columns), where the chain form runs
+    with its THIRD workgroup (round 4: below 48 block columns) and the chain, not the tile kernel, sets the pace: 400 passes by default,
+    JAICOV_SOAK_PASSES for more."""
+    from bundle_adjustment_amd import scene
+    fp = scene.config("cfg3")
+    n = max(400, int(os.environ.get("JAICOV_SOAK_PASSES", "0")))
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    s2 = fp.sigma2apriori
+    ref = None
+    for i in range(n):
+        eng.build(s2, 0.0)
+        dx = eng.solve(False)
+        assert np.isfinite(dx).all(), i
+        if i % 1000 == 999:
+            print(f"soak (config 3): {i + 1} passes", flush=True)
+        if ref is None:
+            ref = dx
+        elif i % 50 == 0:
+            assert np.array_equal(dx, ref)          # deterministic assembly (the default), same system: the same bits
+    st = eng.kernel_stats()
+    eng.close()
+    assert st["flow_retries"] == 0, st
