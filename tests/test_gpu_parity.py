@@ -89,7 +89,7 @@ def test_dataflow_factorisation_on_small_orders(n, monkeypatch):
 
 
 @pytest.mark.parametrize("form", ["chain", "chain2", "chain3", "two_step", "one_kernel", "streams"])
-@pytest.mark.parametrize("n", [384, 1152])
+@pytest.mark.parametrize("n", [384, 1152, 2304])
 def test_factor_tile_by_tile(n, form, monkeypatch):
     """The Cholesky factor itself, every 128 x 128 tile against LAPACK, under every form of the factorisation (the chain
     form's workgroups each own particular tiles: a solve / inverse check alone can hide which one is wrong)."""
