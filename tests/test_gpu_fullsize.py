@@ -93,8 +93,11 @@ def test_cfg4_step_solves_the_normal_equations_and_paths_agree(cfg4, monkeypatch
     dx1_streams, v_streams = _adjust(g, fp, engine.INVERT_NONE)
     g.close()
     scale = np.abs(dx1_full).max()
-    for name, other in (("reduced", dx1_red), ("dense", dx1_dense), ("streams", dx1_streams)):
-        assert np.abs(other - dx1_full).max() < 1e-6 * scale, ("first step", name, np.abs(other - dx1_full).max(), scale)
+    # dx1_full comes from the literal order-18 014 system (no pre-elimination): a differently ordered factorisation of a system with
+    # cond ~ 1e9; each route's step is refined against ITS system, so they agree to the rounding of the two assembled systems (measured 8e-9)
+    # (the densified J'WJ of assembly_mode 1 sums every entry of N in yet another order, over all 250 000 observations at once: 5e-8)
+    for name, other, tol in (("reduced", dx1_red, 3e-8), ("dense", dx1_dense, 2e-7), ("streams", dx1_streams, 3e-8)):
+        assert np.abs(other - dx1_full).max() < tol * scale, ("first step", name, np.abs(other - dx1_full).max(), scale)
     # slots: [3P points | 3 per camera | distortion | 6 per image]; coordinates and camera stations are judged against
     # the extent of the object (2 000 mm), every other parameter against its own magnitude (floor 1.0)
     P3, I6 = 3 * fp.n_points, 6 * fp.n_images
@@ -140,7 +143,8 @@ def test_cfg4_cofactor_matrices(cfg4, converged):
     assert eng.cofactor_order() == fp.n_unknowns
     Qf_sub = eng.get_cofactor_sub(idx)
     sd = np.sqrt(np.diag(Qf_sub))
-    # two inverses of differently ordered systems: agreement to cond * eps (cond(V N V) ~ 1e9), measured 7e-8
+    # two inverses of differently ordered systems: agreement to cond * eps (cond(V N V) ~ 1e9), measured 7e-8 ... 2.5e-7 (the literal
+    # order-18 014 route is the less accurate one: 2.4e-7 from the truth, tests/test_gpu_cfg4_golden.py)
     assert (np.abs(Qf_sub - Qr_sub) / np.outer(sd, sd)).max() < 1e-6
     eo = np.arange(e0, fp.n_unknowns, 37, dtype=np.int32)             # the EO part exists only in FULL
     assert np.all(np.diag(eng.get_cofactor_sub(eo)) > 0)
@@ -166,4 +170,4 @@ def test_cfg4_abandoned_factorisation_is_reported_and_the_engine_stays_usable(cf
     again = eng.solve(False)
     eng.close()
     # two assemblies of the same system differ in the last bits (atomics); through cond 1e9 that is 1e-9..1e-8 of a single step
-    np.testing.assert_allclose(again, ref, rtol=0, atol=1e-7 * np.abs(ref).max())
+    np.testing.assert_allclose(again, ref, rtol=0, atol=1e-9 * np.abs(ref).max())

@@ -77,7 +77,7 @@ def test_reduced_inverse_of_ordinary_images_is_the_block_of_the_full_cofactor(or
         k = eng.cofactor_order()
         assert k == (U - 6 * fp.n_images if inv == engine.INVERT_REDUCED else U)
         Q = packed_to_full(eng.get_cofactor(), k)
-        np.testing.assert_allclose(Q, Qo[:k, :k], rtol=0, atol=1e-8 * np.abs(Qo).max())
+        np.testing.assert_allclose(Q, Qo[:k, :k], rtol=0, atol=1e-9 * np.abs(Qo).max())
     eng.close()
 
 
@@ -193,7 +193,7 @@ def test_simulation_on_ordinary_images_leaves_parameters_and_gives_the_oracles_c
         k = eng.cofactor_order()
         assert k == (U - 6 * fp.n_images if inv == engine.INVERT_REDUCED else U)
         Q = packed_to_full(eng.get_cofactor(), k)
-        np.testing.assert_allclose(Q, Qo[:k, :k], rtol=0, atol=1e-8 * np.abs(Qo).max())
+        np.testing.assert_allclose(Q, Qo[:k, :k], rtol=0, atol=1e-9 * np.abs(Qo).max())
         eng.close()
 
 

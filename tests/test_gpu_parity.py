@@ -227,7 +227,10 @@ def test_estimate_matches_oracle(oracle_mod, name):
     assert abs(r.omega - ro.omega) <= 1e-9 * ro.omega
     U, d = fp.n_unknowns, fp.rank_defect
     Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
-    np.testing.assert_allclose(np.diag(Q)[d:], np.diag(Qref)[d:], rtol=1e-8)
+    # variances at the converged state: 1e-9 on every scene but tiny_block (4.3e-9), where two fp64 assemblies of the same normal matrix
+    # give inverses that far apart (test_gpu_edge_cases.py holds that attribution with extended-precision inverses of both)
+    qerr = float(np.abs(np.diag(Q)[d:] / np.diag(Qref)[d:] - 1.0).max())
+    assert qerr < 1e-8, qerr
     eng.close()
 
 
@@ -238,7 +241,7 @@ def test_estimate_lm_and_simulation(oracle_mod):
     eng = engine.Engine(fp)
     v, r = eng.estimate(lam0=1.0)
     assert r.state == ro.state == 1 and r.iterations == ro.iterations
-    assert (np.abs(v - vo) / np.maximum(np.abs(vo), 1e-3)).max() < 1e-8
+    assert (np.abs(v - vo) / np.maximum(np.abs(vo), 1e-3)).max() < 1e-9
     eng.close()
 
 
@@ -261,7 +264,7 @@ def test_simulation_leaves_parameters_and_gives_the_oracles_cofactors(oracle_mod
     k = eng.cofactor_order()
     Q = packed_to_full(eng.get_cofactor(), k); Qref = packed_to_full(Qo, U)[:k, :k]
     sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
-    assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-8
+    assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
     # one simulated pass through the step-wise ABI as well: the step is exactly zero
     eng.set_parameters(fp.values)
     eng.build(fp.sigma2apriori, 0.0, simulation=True)
@@ -358,7 +361,7 @@ def test_deterministic_assembly_gives_identical_bits(oracle_mod, lam):
     fast = engine.Engine(fp2, deterministic=False)
     fast.set_parameters(fp2.values)
     fast.build(fp2.sigma2apriori, 0.0)
-    np.testing.assert_allclose(fast.solve(False), dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
+    np.testing.assert_allclose(fast.solve(False), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
     fast.close()
 
 
@@ -511,7 +514,7 @@ def test_reduced_inverse_is_the_block_of_the_full_cofactor(oracle_mod, free_netw
     Qref = packed_to_full(Qo, U)[:e0, :e0]
     sd = np.sqrt(np.abs(np.diag(Qref))); sd[sd == 0] = 1.0
     assert (np.abs(Q - Qref)[d:, d:] / np.outer(sd, sd)[d:, d:]).max() < 1e-9
-    assert np.abs(Q - Qref).max() <= 1e-8 * np.abs(Qref).max()
+    assert np.abs(Q - Qref).max() <= 1e-9 * np.abs(Qref).max()
     idx = np.array([d, d + 3, e0 - 1, d + 1], np.int32)
     np.testing.assert_array_equal(eng.get_cofactor_sub(idx), Q[np.ix_(idx, idx)])
     # FULL afterwards still works and agrees on the block
@@ -673,7 +676,7 @@ def test_zernike_odd_orders_and_adjustment_match_oracle(oracle_mod):
     assert (np.abs(Nf - Nof) / np.outer(dg, dg)).max() < 1e-10
     eng.prepare_inverse(engine.INVERT_NONE)
     eng.build(s2, 0.0)
-    np.testing.assert_allclose(eng.solve(False), dxo, rtol=0, atol=1e-8 * np.abs(dxo).max())
+    np.testing.assert_allclose(eng.solve(False), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
     eng.close()
 
 

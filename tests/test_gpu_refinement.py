@@ -187,5 +187,5 @@ def test_expanded_mode_takes_the_literal_route_when_the_exterior_orientations_ou
     np.testing.assert_allclose(dx, dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
     Q = packed_to_full(eng.get_cofactor(), U); Qref = packed_to_full(Qo, U)
     sd = np.sqrt(np.abs(np.diag(Qref)))
-    assert (np.abs(Q - Qref) / np.outer(sd, sd)).max() < 1e-8
+    assert (np.abs(Q - Qref) / np.outer(sd, sd)).max() < 1e-9
     eng.close()

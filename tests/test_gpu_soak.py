@@ -31,8 +31,8 @@ def test_no_factorisation_is_abandoned_over_many_passes(cfg4_scene):
             print(f"soak: {i + 1} passes", flush=True)     # (a long run must not look hung to the GPU pool's watchdog)
         if ref is None:
             ref = dx
-        elif i % 25 == 0:       # same system every pass (no update): the step may differ by the assembly's rounding only
-            assert np.abs(dx - ref).max() <= 1e-7 * np.abs(ref).max()
+        elif i % 25 == 0:       # same system every pass (no update), deterministic assembly (the default) and a fixed order of every tile's updates: the same bits
+            assert np.array_equal(dx, ref), (i, np.abs(dx - ref).max())
     st = eng.kernel_stats()
     eng.close()
     assert st["flow_retries"] == 0, st

@@ -69,4 +69,4 @@ def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle_mod):
     np.testing.assert_allclose(r0[base:base + U], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
     Q = r0[base + U:]
     assert Q.size == Qo.size
-    np.testing.assert_allclose(Q, Qo, rtol=0, atol=1e-8 * np.abs(Qo).max())
+    np.testing.assert_allclose(Q, Qo, rtol=0, atol=1e-9 * np.abs(Qo).max())
