@@ -755,12 +755,10 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             for (int ip : blk_ip_list)
                 for (int a = 0; a < 3; a++) ipcol[(size_t)3 * ip + a] = D->point_col[3 * D->ip_point[ip] + a];
             // per record and column chunk: the range of partner positions (the block is stored in column order)
-            const int cw_rt = std::max(64, std::min(PP_CW, 6400)) / 4 * 4;  // 3 * cw doubles of LDS (<= 150 KB), quarters for the DET form
-            e->pp.cw = cw_rt;
+            int cw_rt = std::max(64, std::min(PP_CW, 6400)) / 4 * 4;  // 3 * cw doubles of LDS (<= 150 KB), quarters for the DET form
             // XCD-partitioned block order (assemble.hip): measured no faster (3.24 vs 3.26 ms at 960 columns, slower where the chunks
             // do not divide evenly over eight XCDs) and FETCH_SIZE fell by 6 % only: the partner records are not what the kernel waits for
             e->pp.xcd_map = 0;
-            const int n_chunks = (cmax - cmin + cw_rt) / cw_rt;
             const int NOCOL = 1 << 30;
             std::vector<int32_t> lo_col(D->n_image_points, NOCOL), hi_col(D->n_image_points, -1);
             for (int ip : blk_ip_list)
@@ -768,6 +766,33 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
                     const int c = ipcol[(size_t)3 * ip + a];
                     if (c >= 0) { lo_col[ip] = std::min(lo_col[ip], c); hi_col[ip] = std::max(hi_col[ip], c); }
                 }
+            // The strip width follows the scene: a wave takes the partners of ONE image inside the strip's columns, 64 at a time.  With
+            // random visibility the default width holds 55 +- 7 of an image's 500 points; on a block flown in strips the
+            // points of an image are neighbours in column order and sit in two or three strips, hundreds in each -- eight segments of one
+            // image inside one turn of the deterministic form.  Then the strip is narrowed until an image's partners in a strip are about
+            // one wave again (never below 256 columns: the range table has one entry per image point and strip).
+            {
+                std::vector<int32_t> per_block;                      // columns spanned by the partners of a block, and how many there are
+                double span = 0.0, cnt = 0.0;
+                for (size_t t = 0; t < blk_list.size(); t++) {
+                    const int g = blk_list[t], ipb = D->blk_ip_begin[g], mp = D->blk_ip_begin[g + 1] - ipb;
+                    // distinct default-width strips touched by this block's points
+                    int touched = 0, last = -1;
+                    for (int j = 0; j < mp; j++) {
+                        if (lo_col[ipb + j] == NOCOL) continue;
+                        const int c = (lo_col[ipb + j] - cmin) / cw_rt;
+                        if (c != last) { ++touched; last = c; }
+                    }
+                    if (touched > 0) { span += touched; cnt += mp; }
+                }
+                const double per_strip = span > 0 ? cnt / span : 0.0;   // mean partners of an image per touched strip
+                if (per_strip > 96.0) {
+                    int cw2 = (int)(cw_rt * 56.0 / per_strip) / 64 * 64;
+                    cw_rt = std::max(256, std::min(cw_rt, cw2));
+                }
+            }
+            e->pp.cw = cw_rt;
+            const int n_chunks = (cmax - cmin + cw_rt) / cw_rt;
             std::vector<int32_t> chunk_lo((size_t)blk_list.size() * n_chunks), chunk_hi((size_t)blk_list.size() * n_chunks);
             std::vector<int32_t> blk_pos(D->n_image_blocks, -1);
             for (size_t t = 0; t < blk_list.size(); t++) {
@@ -1800,6 +1825,7 @@ extern "C" int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t 
     }
     if (n >= 11) stats[10] = e->last_refine_correction;
     if (n >= 12) stats[11] = (double)e->refine_steps;      // refinement steps per solve the engine actually runs (option `refinement`, clamped)
+    if (n >= 13) stats[12] = (double)e->pp.cw;             // columns of one LDS strip of the point x point gather (chosen at create from the scene)
     if (reset) e->solver.stat_launches = e->solver.stat_ms = e->solver.stat_flops = e->dm_stat_passes = e->dm_stat_ms = e->dm_stat_flops = 0.0;
     return JAICOV_OK;
 }

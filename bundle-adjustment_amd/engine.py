@@ -307,11 +307,11 @@ class Engine:
         self._chk(self.L.jaicov_neq_set_profiling(self._h, int(on)))
 
     def kernel_stats(self, reset=False):
-        st = np.zeros(12)
-        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 12, int(reset)))
+        st = np.zeros(13)
+        self._chk(self.L.jaicov_neq_kernel_stats(self._h, _p(st), 13, int(reset)))
         return {"launches": st[0], "ms": st[1], "flops": st[2], "dense_passes": st[3], "dense_gemm_ms": st[4], "dense_flops": st[5],
                 "flow_retries": int(st[6]), "flow_stale_events": int(st[7]), "flow_stale_confirmed": int(st[8]),
-                "flow_rescued": int(st[9]), "last_refinement_correction": float(st[10]), "refine_steps": int(st[11])}
+                "flow_rescued": int(st[9]), "last_refinement_correction": float(st[10]), "refine_steps": int(st[11]), "gather_strip_columns": int(st[12])}
 
     def cancel(self):
         """``BundleAdjustment.interrupt()`` (BundleAdjustment.java:1455): the running / next ``estimate`` ends with state -1."""

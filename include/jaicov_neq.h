@@ -343,7 +343,8 @@ int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
  * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == 0 ([7]..[9] are informational:
  * the slow-path poll also finds flags that were simply set late); bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
  * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).  With n >= 12: [11] the refinement steps
- * per solve the engine runs (option `refinement` after clamping).                                                                */
+ * per solve the engine runs (option `refinement` after clamping).  With n >= 13: [12] the strip width (columns) of the point x point
+ * gather, chosen at create from how an image's points spread over the columns.                                                   */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 /* What jaicov_neq_create spent (ms, wall clock of the host): [0] the whole call, [1] host time inside the uploads of the dense
  * dispersions (pageable host memory -> device), [2] dispersions -> weights altogether (upload + batched inversion, DOPG:82-86),
