@@ -19,6 +19,14 @@ constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry
 enum { FACTOR_DEFAULT = 0, FACTOR_STREAMS = 1, FACTOR_TWO_STEP = 2, FACTOR_ONE_KERNEL = 3, FACTOR_CHAIN2 = 4, FACTOR_CHAIN3 = 5 };
 int factor_form();                 // JAICOV_FACTOR_FORM (dense.hip): test hook for the non-default forms of the factorisation
 
+// Streams are kept for the life of the process (dense.hip): creating one costs 12-35 ms on this stack (a hardware queue is set up), destroying
+// one 5 ms, and an engine needs eight -- 100 ms of the 225 ms an engine creation took at BASELINE config 4.  stream_acquire hands out a
+// stream nobody else holds (a cached one if there is one of that kind for the current device, else a new one; nullptr if it cannot
+// be created); stream_release synchronises it and puts it back.
+enum { STREAM_PLAIN = 0, STREAM_HIGH_PRIORITY = 1, STREAM_UPDATE_CUS = 2, STREAM_DIAGONAL_CUS = 3, STREAM_KINDS = 4 };
+hipStream_t stream_acquire(int kind);
+void stream_release(int kind, hipStream_t s);
+
 struct DenseSolver {
     hipStream_t stream = nullptr;
     int n = 0;                 // rows of the storage, multiple of 128: nfact, plus 128 right-hand-side rows if `aug`

@@ -6,6 +6,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <vector>
+
 #include "gemm_f64.h"
 #include "potrf_diag.h"
 
@@ -821,6 +825,59 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double *M, long ld, int
 // JAICOV_FACTOR_FORM = streams | two_step | one_kernel | chain2 | chain3: the forms of the factorisation other than the default (dataflow, chain
 // form), each named by a case of tests/test_gpu_parity.py (test_factor_tile_by_tile, test_config3_step_against_oracle).  Read at
 // every call: the tests switch it between engines of one process.
+namespace {
+std::mutex g_stream_mutex;
+std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (device, kind) -> idle streams
+}
+
+hipStream_t stream_acquire(int kind) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        std::vector<hipStream_t> &idle = g_stream_pool[{dev, kind}];
+        if (!idle.empty()) {
+            hipStream_t s = idle.back();
+            idle.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    hipError_t err = hipSuccess;
+    if (kind == STREAM_PLAIN) {
+        err = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    } else if (kind == STREAM_HIGH_PRIORITY) {
+        int least = 0, greatest = 0;
+        err = hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (err == hipSuccess) err = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, greatest);
+    } else {
+        // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask is CU i/8 of XCD i%8): the trailing
+        // updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.  (Reserving fewer CUs was
+        // measured: one or two reserved CUs cost 5 ms per factorisation at config 4, eight cost the update 3 % of the chip.)
+        uint32_t mask[8];
+        for (int w = 0; w < 8; w++) mask[w] = kind == STREAM_UPDATE_CUS ? 0xFFFFFFFFu : 0u;
+        mask[7] = kind == STREAM_UPDATE_CUS ? 0x00FFFFFFu : 0xFF000000u;
+        err = hipExtStreamCreateWithCUMask(&s, 8, mask);
+    }
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return s;
+}
+
+void stream_release(int kind, hipStream_t s) {
+    if (!s) return;
+    int dev = 0;
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetDevice(&dev) != hipSuccess) {      // a stream in an error state is not worth keeping
+        (void)hipGetLastError();
+        hipStreamDestroy(s);
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_stream_pool[{dev, kind}].push_back(s);
+}
+
 int factor_form() {
     const char *e = getenv("JAICOV_FACTOR_FORM");
     if (!e) return FACTOR_DEFAULT;
@@ -861,24 +918,17 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 24;      // (the tests lower it)
     const bool flow_wanted = factor_form() != FACTOR_STREAMS && nfact / 128 >= flow_from;
     {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&pstream, hipStreamNonBlocking, greatest));
-        // CU reservation (measured on MI355X/ROCm 7.2: bit i of the 256-bit mask is CU i/8 of XCD i%8): the trailing
-        // updates get CUs 0..30 of every XCD, the diagonal-block kernel CU 31 of every XCD.  (Reserving fewer CUs was
-        // measured: one or two reserved CUs cost 5 ms per factorisation at config 4, eight cost the update 3 % of the chip.)
+        pstream = stream_acquire(STREAM_HIGH_PRIORITY);
+        if (!pstream) return hipErrorUnknown;
+        // reserved CUs: CU 31 of every XCD for the diagonal blocks, the other 31 for the trailing updates (stream_acquire)
         if (nfact >= 2048 || flow_wanted) {
-            uint32_t upd[8], dia[8];
-            for (int w = 0; w < 8; w++) { upd[w] = 0xFFFFFFFFu; dia[w] = 0u; }
-            // reserved: CU 31 of every XCD (8 CUs; reserving one or two cost the stream-scheduled factorisation 5 ms at config 4)
-            reserved_cus = 8; upd[7] = 0x00FFFFFFu; dia[7] = 0xFF000000u;
-            if (hipExtStreamCreateWithCUMask(&ustream, 8, upd) != hipSuccess) ustream = nullptr;
-            if (hipExtStreamCreateWithCUMask(&dstream, 8, dia) != hipSuccess) dstream = nullptr;
+            reserved_cus = 8;
+            ustream = stream_acquire(STREAM_UPDATE_CUS);
+            dstream = stream_acquire(STREAM_DIAGONAL_CUS);
             if (!ustream || !dstream) {
-                if (ustream) hipStreamDestroy(ustream);
-                if (dstream) hipStreamDestroy(dstream);
+                stream_release(STREAM_UPDATE_CUS, ustream);
+                stream_release(STREAM_DIAGONAL_CUS, dstream);
                 ustream = dstream = nullptr;
-                (void)hipGetLastError();
             }
         }
     }
@@ -920,9 +970,9 @@ void DenseSolver::release() {
     prof_ev.clear();
     for (auto ev : sync_ev) hipEventDestroy(ev);
     sync_ev.clear();
-    if (pstream) hipStreamDestroy(pstream);
-    if (ustream) hipStreamDestroy(ustream);
-    if (dstream) hipStreamDestroy(dstream);
+    stream_release(STREAM_HIGH_PRIORITY, pstream);
+    stream_release(STREAM_UPDATE_CUS, ustream);
+    stream_release(STREAM_DIAGONAL_CUS, dstream);
     pstream = ustream = dstream = nullptr;
     L = invd = W = Q = nullptr;
     if (pm_e0) hipEventDestroy(pm_e0);

@@ -373,7 +373,8 @@ static int invert_dispersions(jaicov_engine *e, std::vector<DispItem> &items) {
     double up_ms = 0.0;
     std::stable_sort(items.begin(), items.end(), [](const DispItem &a, const DispItem &b) { return (a.m + 127) / 128 < (b.m + 127) / 128; });
     hipStream_t cstream = nullptr;
-    HIPE(e, hipStreamCreateWithFlags(&cstream, hipStreamNonBlocking));
+    cstream = jaicov::stream_acquire(jaicov::STREAM_PLAIN);
+    if (!cstream) FAIL(e, JAICOV_ERR_DEVICE, "no stream for the dispersion uploads");
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     for (int b = 0; b < 2; b++) {
         HIPE(e, hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming));
@@ -436,7 +437,7 @@ static int invert_dispersions(jaicov_engine *e, std::vector<DispItem> &items) {
         g0 = g1;
     }
     for (int b = 0; b < 2; b++) { hipEventDestroy(ev_up[b]); hipEventDestroy(ev_free[b]); }
-    hipStreamDestroy(cstream);
+    jaicov::stream_release(jaicov::STREAM_PLAIN, cstream);
     e->create_ms[1] = up_ms;
     e->create_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count();
     if (status != JAICOV_OK) FAIL(e, status, msg);
@@ -465,7 +466,7 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     if (e->ev_r1) hipEventDestroy(e->ev_r1);
     if (e->d_refP) hipFree(e->d_refP);
     if (e->d_expF) hipFree(e->d_expF);
-    if (e->stream) hipStreamDestroy(e->stream);
+    jaicov::stream_release(jaicov::STREAM_PLAIN, e->stream);
     delete e;
 }
 
@@ -481,7 +482,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
     HIPE(e, hipGetDeviceProperties(&prop, e->device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         FAIL(e, JAICOV_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
-    HIPE(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->stream = jaicov::stream_acquire(jaicov::STREAM_PLAIN);
+    if (!e->stream) FAIL(e, JAICOV_ERR_DEVICE, "no stream");
     for (auto &evt : e->ev) HIPE(e, hipEventCreate(&evt));
     HIPE(e, hipEventCreateWithFlags(&e->ev_first, hipEventDisableTiming));
     HIPE(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
