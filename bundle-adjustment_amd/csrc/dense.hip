@@ -914,8 +914,10 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     // dataflow form then pays its start-up (two launches, a host handshake, ~0.15 ms).  Measured on MI355X
     // (scripts/flow_trace.py, ms per factorisation dataflow / streams): order 1024 0.76 / 0.62, 2048 1.32 / 1.28,
     // 3072 1.94 / 2.00, 3712 2.37 / 2.50, 5120 3.33 / 3.75, 6144 4.07 / 4.78, 8192 5.95 / 7.92, 15104 22.3 / 26.3
-    // -> from 24 block columns on.
-    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 24;      // (the tests lower it)
+    // -> from 24 block columns on (rounds 2 and 3).  Round 4 (diagonal block 41 -> 27 us, third chain workgroup below 48 block columns):
+    // order 640 0.43 / 0.39, 1024 0.65 / 0.59, 1152 0.70 / 0.69, 1280 0.75 / 0.77, 1408 0.82 / 0.83, 1536 0.82 / 0.92, 2048 1.10 / 1.25,
+    // 2560 1.32 / 1.59, 3072 1.55 / 1.94 -> from 12 block columns on.
+    const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 12;      // (the tests lower it)
     const bool flow_wanted = factor_form() != FACTOR_STREAMS && nfact / 128 >= flow_from;
     {
         pstream = stream_acquire(STREAM_HIGH_PRIORITY);
