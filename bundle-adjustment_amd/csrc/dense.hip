@@ -828,6 +828,17 @@ __global__ __launch_bounds__(256) void symmetrize_kernel(double *M, long ld, int
 namespace {
 std::mutex g_stream_mutex;
 std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (device, kind) -> idle streams
+// The idle streams are destroyed when this library's static objects are (at exit, BEFORE those of the HIP runtime it depends on and before
+// a profiler's finalisation: under rocprofv3 a process that left streams to the runtime's own teardown ended in a segmentation fault
+// inside __cxa_finalize, after the tool had written its output).
+struct StreamPoolCleanup {
+    ~StreamPoolCleanup() {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        for (auto &kv : g_stream_pool)
+            for (hipStream_t s : kv.second) (void)hipStreamDestroy(s);
+        g_stream_pool.clear();
+    }
+} g_stream_pool_cleanup;
 }
 
 hipStream_t stream_acquire(int kind) {

@@ -234,6 +234,23 @@ def test_estimate_matches_oracle(oracle_mod, name):
     eng.close()
 
 
+@pytest.mark.parametrize("name", ["tiny", "tiny_block"])
+@pytest.mark.parametrize("max_iter", [1, 2])
+def test_iteration_limit_ends_like_the_reference(oracle_mod, name, max_iter):
+    """maximalNumberOfIterations reached before the step falls below sqrt(eps) (BundleAdjustment.java:228, 344-355): the same state
+    (NO_CONVERGENCE, -4), the same number of passes and the same last iterate as the oracle's restatement of that loop."""
+    fp = scene.config(name)
+    o = oracle_mod.Oracle(fp)
+    vo, _, ro = o.estimate(max_iter=max_iter, invert=False)
+    eng = engine.Engine(fp)
+    v, r = eng.estimate(max_iter=max_iter, invert=engine.INVERT_NONE)
+    assert r.state == ro.state and r.iterations == ro.iterations
+    assert ro.state == -4, ro.state
+    assert (np.abs(v - vo) / np.maximum(np.abs(vo), 1e-3)).max() < 1e-9
+    assert abs(r.max_abs_dx - ro.max_abs_dx) <= 1e-8 * ro.max_abs_dx
+    eng.close()
+
+
 def test_estimate_lm_and_simulation(oracle_mod):
     fp = scene.config("tiny")
     o = oracle_mod.Oracle(fp)
