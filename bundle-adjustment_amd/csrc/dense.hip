@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -831,11 +832,14 @@ std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (
 // The idle streams are destroyed when this library's static objects are (at exit, BEFORE those of the HIP runtime it depends on and before
 // a profiler's finalisation: under rocprofv3 a process that left streams to the runtime's own teardown ended in a segmentation fault
 // inside __cxa_finalize, after the tool had written its output).
+std::vector<hipStream_t> g_all_streams;       // every stream stream_acquire has created and nobody has destroyed: idle ones and those of live (or leaked) engines
+std::map<hipStream_t, int> g_stream_device;    // ... and the device each belongs to (a stream is filed under ITS device whatever the caller's current one is)
 struct StreamPoolCleanup {
     ~StreamPoolCleanup() {
         std::lock_guard<std::mutex> lock(g_stream_mutex);
-        for (auto &kv : g_stream_pool)
-            for (hipStream_t s : kv.second) (void)hipStreamDestroy(s);
+        for (hipStream_t s : g_all_streams) (void)hipStreamDestroy(s);
+        g_all_streams.clear();
+        g_stream_device.clear();
         g_stream_pool.clear();
     }
 } g_stream_pool_cleanup;
@@ -874,19 +878,27 @@ hipStream_t stream_acquire(int kind) {
         (void)hipGetLastError();
         return nullptr;
     }
+    std::lock_guard<std::mutex> lock(g_stream_mutex);
+    g_all_streams.push_back(s);
+    g_stream_device[s] = dev;
     return s;
 }
 
 void stream_release(int kind, hipStream_t s) {
     if (!s) return;
-    int dev = 0;
-    if (hipStreamSynchronize(s) != hipSuccess || hipGetDevice(&dev) != hipSuccess) {      // a stream in an error state is not worth keeping
+    if (hipStreamSynchronize(s) != hipSuccess) {      // a stream in an error state is not worth keeping
         (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_stream_mutex);
+            g_all_streams.erase(std::remove(g_all_streams.begin(), g_all_streams.end(), s), g_all_streams.end());
+            g_stream_device.erase(s);
+        }
         hipStreamDestroy(s);
         return;
     }
     std::lock_guard<std::mutex> lock(g_stream_mutex);
-    g_stream_pool[{dev, kind}].push_back(s);
+    const auto it = g_stream_device.find(s);
+    g_stream_pool[{it == g_stream_device.end() ? 0 : it->second, kind}].push_back(s);
 }
 
 int factor_form() {
