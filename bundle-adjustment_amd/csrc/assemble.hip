@@ -135,7 +135,7 @@ __global__ __launch_bounds__(T_NT) void blk_T_kernel(DevProblem p, const int32_t
     const int g = blk_list[blockIdx.y];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
     const int rbase = blockIdx.x * (T_NT * T_TR) + threadIdx.x;
-    if ((int)blockIdx.x * (T_NT * T_TR) >= m) return;
+    if ((int)blockIdx.x * (T_NT * T_TR) >= m || p.blk_w_offset[g] < 0) return;      // (block-diagonal weights: blk_T_diag_kernel)
     const long S = p.n_ip;
     const int img = p.ip_image[ipb], cam = p.image_camera[img];
     const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void blk_T_mfma_kernel(DevProblem p, const 
     __shared__ double Ac[64 * TM_LD];
     const int g = blk_list[blockIdx.y];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
-    if ((int)blockIdx.x * 256 >= m) return;
+    if ((int)blockIdx.x * 256 >= m || p.blk_w_offset[g] < 0) return;      // (block-diagonal weights: blk_T_diag_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     const long S = p.n_ip;
     const int img = p.ip_image[ipb], cam = p.image_camera[img];
@@ -298,6 +298,28 @@ __global__ __launch_bounds__(256, 2) void blk_T_mfma_kernel(DevProblem p, const 
             out[l15] = acc[t][0][r];
             if (16 + l15 < KC_LD) out[16 + l15] = acc[t][1][r];
         }
+}
+
+// T = inv(D) [A_c | w] of an image whose weights are BLOCK-DIAGONAL (an ordinary image served as an image block, DevProblem::ip_w3): the two
+// rows of an image point are its 2 x 2 weight times its own two rows of [A_c | w] -- one thread per image point and column, no sum over the
+// image.  grid (ceil(points / 8), n_list), block (32 columns, 8 points).
+__global__ __launch_bounds__(256) void blk_T_diag_kernel(DevProblem p, const int32_t *__restrict__ blk_list, const double *__restrict__ rowsA,
+                                                         const double *__restrict__ rowsW, double *__restrict__ T) {
+    const int g = blk_list[blockIdx.y];
+    if (p.blk_w_offset[g] >= 0) return;
+    const int ipb = p.blk_ip_begin[g], mp = p.blk_ip_begin[g + 1] - ipb;
+    const int o = blockIdx.x * 8 + threadIdx.y, c = threadIdx.x;
+    if (o >= mp || c >= KC_LD) return;
+    const long S = p.n_ip;
+    const int img = p.ip_image[ipb], cam = p.image_camera[img];
+    const int kc = 9 + p.cam_dist_begin[cam + 1] - p.cam_dist_begin[cam];
+    double x0 = 0.0, x1 = 0.0;
+    if (c < kc) { x0 = rowsA[(long)(2 * shared_local(c)) * S + ipb + o]; x1 = rowsA[(long)(2 * shared_local(c) + 1) * S + ipb + o]; }
+    else if (c == kc) { x0 = rowsW[ipb + o]; x1 = rowsW[S + ipb + o]; }
+    const double *w = p.ip_w3 + 3 * (long)(ipb + o);
+    double *out = T + ((long)2 * (ipb + o)) * KC_LD + c;
+    out[0] = w[0] * x0 + w[1] * x1;
+    out[KC_LD] = w[1] * x0 + w[2] * x1;
 }
 
 // B2: shared block S_cc = A_c' T_c, n_c = A_c' T_w.  Two launches, and no atomics: every image block deals its rows to
@@ -470,9 +492,17 @@ __global__ __launch_bounds__(192) void blk_pp_kernel(DevProblem p, const int32_t
     const int q = blockIdx.x * 64 + qq;
     if (q > pp) return;
     const long S = p.n_ip;
-    const double *P = p.blk_w + p.blk_w_offset[g];
-    const d2_t P0 = *reinterpret_cast<const d2_t *>(P + (long)(2 * pp) * m + 2 * q);
-    const d2_t P1 = *reinterpret_cast<const d2_t *>(P + (long)(2 * pp + 1) * m + 2 * q);
+    d2_t P0 = {0.0, 0.0}, P1 = {0.0, 0.0};
+    if (p.blk_w_offset[g] >= 0) {
+        const double *P = p.blk_w + p.blk_w_offset[g];
+        P0 = *reinterpret_cast<const d2_t *>(P + (long)(2 * pp) * m + 2 * q);
+        P1 = *reinterpret_cast<const d2_t *>(P + (long)(2 * pp + 1) * m + 2 * q);
+    } else if (q == pp) {      // block-diagonal weights: the pair of a point with itself is all there is
+        const double *w = p.ip_w3 + 3 * (long)(ipb + pp);
+        P0.x = w[0]; P0.y = w[1]; P1.x = w[1]; P1.y = w[2];
+    } else {
+        return;
+    }
     const int ipp = ipb + pp, ipq = ipb + q;
     const int ptp = p.ip_point[ipp], ptq = p.ip_point[ipq];
     const int cq = p.point_col[3 * ptq + b];
@@ -510,16 +540,25 @@ struct PPData {           // what one thread needs of one partner point q
     d2_t uq[FUSED ? 6 : 1];   // rows 2q, 2q+1 of U (6 values each)
 };
 
-template <bool FUSED>
+// MIXED: some image blocks have block-diagonal weights in compact form (r.poff < 0, DevProblem::ip_w3: an ordinary image served as a block):
+// nothing is streamed for them, the pair of the row point with itself carries its 2 x 2 weight and every other pair the rank-6 term only.
+template <bool FUSED, bool MIXED>
 __device__ __forceinline__ void pp_load(PPData<FUSED> &d, const DevProblem &p, const PPRecord &r, const int32_t *__restrict__ ipcol,
                                         const double *__restrict__ rowsA, const double *__restrict__ Ubuf, int q, int qend,
                                         const double *__restrict__ ug) {
     const long S = p.n_ip;
     if (q < qend) {
-        const int m = 2 * r.mp;
-        const double *P = p.blk_w + r.poff + (long)(2 * r.lp) * m + 2 * q;
-        d.P0 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(P));      // streamed exactly once over the launch
-        d.P1 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(P + m));
+        if (!MIXED || r.poff >= 0) {
+            const int m = 2 * r.mp;
+            const double *P = p.blk_w + r.poff + (long)(2 * r.lp) * m + 2 * q;
+            d.P0 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(P));      // streamed exactly once over the launch
+            d.P1 = __builtin_nontemporal_load(reinterpret_cast<const d2_t *>(P + m));
+        } else {
+            const double *w = p.ip_w3 + 3 * (long)(r.ipb + r.lp);                      // the same for every lane
+            const bool self = q == r.lp;
+            d.P0.x = self ? w[0] : 0.0; d.P0.y = self ? w[1] : 0.0;
+            d.P1.x = self ? w[1] : 0.0; d.P1.y = self ? w[2] : 0.0;
+        }
 #pragma unroll
         for (int b = 0; b < 3; b++) {
             d.cq[b] = ipcol[3 * (long)(r.ipb + q) + b];
@@ -624,7 +663,7 @@ __device__ __forceinline__ int2 pp_range(const int2 *range, long idx) {
     return make_int2(__builtin_amdgcn_readfirstlane(g.x), __builtin_amdgcn_readfirstlane(g.y));
 }
 
-template <bool FUSED, bool DET = false>
+template <bool FUSED, bool DET = false, bool MIXED = false>
 __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             const double *__restrict__ Ubuf, double sigma2, double *__restrict__ N) {
     extern __shared__ double strip[];              // 3 rows x cw columns, + one word (DET: the turn, see below)
@@ -690,7 +729,7 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
         double apc[6], upc[12];
         int js = g1.x;                      // first partner of the segment at hand
         bool first = true;                  // ... which is the first of its image (DET: the turn has not been taken yet)
-        pp_load<FUSED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, js + lane, g1.y, pp.ug);
+        pp_load<FUSED, MIXED>(cur, p, r1, pp.ipcol, rowsA, Ubuf, js + lane, g1.y, pp.ug);
         pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane), sigma2, apc, upc);
         for (;;) {
             const bool more = js + 64 < g1.y;
@@ -706,7 +745,7 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
             rn.poff = more ? r1.poff : r2.poff; rn.pad2 = 0;
             const int qn = more ? js + 64 : g2.x, qe = more ? g1.y : g2.y;
             if (more || adv) {
-                pp_load<FUSED>(nxt, p, rn, pp.ipcol, rowsA, Ubuf, qn + lane, qe, pp.ug);
+                pp_load<FUSED, MIXED>(nxt, p, rn, pp.ipcol, rowsA, Ubuf, qn + lane, qe, pp.ug);
                 if (adv) rown = pp_fetch_row<FUSED>(p, r2, rowsA, Ubuf, lane);
             }
             if constexpr (DET) {
@@ -907,12 +946,16 @@ __global__ __launch_bounds__(256) void omega_block_kernel(DevProblem p, const in
     const int g = blk_list[blockIdx.y];
     const int ipb = p.blk_ip_begin[g], m = 2 * (p.blk_ip_begin[g + 1] - ipb);
     const int r = blockIdx.x * 256 + threadIdx.x;
-    const double *P = p.blk_w + p.blk_w_offset[g];
     const double *v = vbuf + 2 * (long)ipb;
     double s = 0.0;
-    if (r < m) {
+    if (r < m && p.blk_w_offset[g] >= 0) {
+        const double *P = p.blk_w + p.blk_w_offset[g];
         for (int k = 0; k < m; k++) s += P[(long)k * m + r] * v[k];
         s *= v[r] * sigma2;
+    } else if (r < m) {        // block-diagonal weights (DevProblem::ip_w3): row r of the 2 x 2 block of its image point
+        const double *w = p.ip_w3 + 3 * (long)(ipb + (r >> 1));
+        const double pr0 = (r & 1) ? w[1] : w[0], pr1 = (r & 1) ? w[2] : w[1];
+        s = (pr0 * v[r & ~1] + pr1 * v[r | 1]) * v[r] * sigma2;
     }
     red[threadIdx.x] = s;
     __syncthreads();
@@ -965,6 +1008,8 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
     const bool t_vector = form == ASSEMBLY_T_VECTOR;
     if (t_vector) hipLaunchKernelGGL(blk_T_kernel, dim3((max_m + T_NT * T_TR - 1) / (T_NT * T_TR), n_list), dim3(T_NT), 0, s, p, blk_list, rowsA, rowsW, T);
     else hipLaunchKernelGGL(blk_T_mfma_kernel, dim3((max_m + 255) / 256, n_list), dim3(256), 0, s, p, blk_list, rowsA, rowsW, T);
+    if (p.ip_w3)      // images with block-diagonal weights (both T kernels leave them alone)
+        hipLaunchKernelGGL(blk_T_diag_kernel, dim3((max_m / 2 + 7) / 8, n_list), dim3(32, 8), 0, s, p, blk_list, rowsA, rowsW, T);
     DevProblem q = p;
     double s2 = sigma2;
     if (schur) {   // EO pre-elimination: weights become P' = sigma2 Dinv - U U', T becomes P' [A_r | w]
@@ -1014,10 +1059,16 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
         const size_t lds = (size_t)3 * pp.cw * sizeof(double) + sizeof(double);      // + the DET form's turn word
         const bool det = pp.det != 0;
         if (schur && !sb.materialise) {   // the downdate P' = sigma2 Dinv - U U' on the fly: weights = Dinv, factor sigma2 inside
-            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
+            const bool mixed = p.ip_w3 != nullptr;       // (a separate instance: the dense-only kernel keeps its code and its registers)
+            if (det && mixed) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
+            else if (mixed) hipLaunchKernelGGL((blk_pp_gather_kernel<true, false, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
+            else if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
             else hipLaunchKernelGGL((blk_pp_gather_kernel<true, false>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
         } else {
-            if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<false, true>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+            const bool mixed = q.ip_w3 != nullptr;
+            if (det && mixed) hipLaunchKernelGGL((blk_pp_gather_kernel<false, true, true>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+            else if (mixed) hipLaunchKernelGGL((blk_pp_gather_kernel<false, false, true>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
+            else if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<false, true>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
             else hipLaunchKernelGGL((blk_pp_gather_kernel<false, false>), gg, gb, lds, s, q, pp, rowsA, (const double *)nullptr, s2, N);
         }
     } else {

@@ -26,8 +26,10 @@ struct DevProblem {
     const int32_t *ip_image, *ip_point;
     const double *ip_x, *ip_y, *ip_var_x, *ip_var_y, *ip_rho;
     const int32_t *blk_ip_begin;       // [n_blocks+1]
-    const int64_t *blk_w_offset;       // [n_blocks] offset of the block's D^-1 (m x m row-major) in blk_w
+    const int64_t *blk_w_offset;       // [n_blocks] offset of the block's D^-1 (m x m row-major) in blk_w; < 0: block-diagonal weights, see ip_w3
     const double *blk_w;
+    const double *ip_w3;               // [3 n_ip] or null: (w00, w01, w11) of inv([[vx, rho s], [rho s, vy]]) per image point -- the weights of an
+                                       // ORDINARY image served as an image block (engine.hip): 2 x 2 blocks on the diagonal, nothing else stored
     const int32_t *sb_a, *sb_b;
     const double *sb_len, *sb_var;
     const int32_t *dg_row_begin, *dg_slot;
@@ -40,7 +42,7 @@ struct DevProblem {
 // tables of the atomics-free point x point gather (assemble.hip, blk_pp_gather_kernel); null = use the atomic kernel
 struct PPRecord {          // one (object point, image block) incidence, 32 bytes
     int32_t ipb, mp, lp, pad;   // first image point of the block, points in the block, local index of the point
-    int64_t poff;               // offset of the block's Dinv in blk_w
+    int64_t poff;               // offset of the block's Dinv in blk_w (< 0: block-diagonal weights, DevProblem::ip_w3)
     int64_t pad2;
 };
 #ifndef JAICOV_PP_CW

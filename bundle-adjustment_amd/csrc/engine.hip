@@ -237,6 +237,7 @@ struct jaicov_engine {
     std::vector<int> h_blk_images;   // image of every block handled by this engine
     std::vector<int32_t> h_caller_block; // internal image block -> the caller's block index (-1: an ordinary image served as a block); empty: identity
     bool synthesized_blocks = false;     // ordinary image groups are served as image blocks with block-diagonal weights (create_impl)
+    bool compact_blocks = false;         // ... and their weights are kept as 2 x 2 blocks (DevProblem::ip_w3), not as m x m matrices
     std::vector<int32_t> h_perm_local;   // per image point of a dense block: engine position -> caller's position inside the block (empty: identity)
     std::vector<int64_t> h_blk_w_off;    // offset of every image block's weight in p.blk_w
     std::vector<int32_t> h_blk_ip_begin; // copy of blk_ip_begin
@@ -345,6 +346,22 @@ __global__ void store_inv_batched_kernel(const DispDesc *__restrict__ desc, cons
     const DispDesc dd = desc[blockIdx.z];
     if (i >= dd.m || j >= dd.m) return;
     dd.dst[(long)i * dd.m + j] = Qb[(long)blockIdx.z * msz + (long)i * ld + j];
+}
+
+// The same weights in compact form (DevProblem::ip_w3): (w00, w01, w11) per image point, nothing else stored -- an ordinary image with m
+// rows then costs 1.5 m doubles instead of m^2, and T = inv(D) [A_c | w] two multiplications per entry instead of a dense product.
+__global__ void fill_ip_w3_kernel(const double *__restrict__ vx, const double *__restrict__ vy, const double *__restrict__ rho, int n_ip,
+                                  double *__restrict__ out) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_ip) return;
+    const double x = vx[q], y = vy[q], c = rho[q];
+    double w00, w01, w11;
+    if (c == 0.0) { w00 = 1.0 / x; w01 = 0.0; w11 = 1.0 / y; }
+    else {
+        const double inv_det = 1.0 / ((1.0 - c * c) * x * y);
+        w00 = inv_det * y; w01 = -inv_det * c * sqrt(x * y); w11 = inv_det * x;
+    }
+    out[3 * (long)q] = w00; out[3 * (long)q + 1] = w01; out[3 * (long)q + 2] = w11;
 }
 
 // inv(D) of an ordinary image served as a block: 2 x 2 blocks [[vx, rho s], [rho s, vy]]^-1, s = sqrt(vx vy), on the diagonal
@@ -589,7 +606,8 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
                 ok = cnt >= 3 && 2 * cnt <= 4096;
                 syn_bytes += 4 * cnt * cnt * (int64_t)sizeof(double);
             }
-            ok = ok && any && syn_bytes <= ((int64_t)16 << 30);
+            // (the dense form of the block-diagonal weights -- the alternative assembly forms only -- needs m^2 doubles per image)
+            ok = ok && any && (assembly_form() == ASSEMBLY_DEFAULT || assembly_form() == ASSEMBLY_NO_FORK || syn_bytes <= ((int64_t)16 << 30));
         }
         if (ok) {
             syn_begin.push_back(0);
@@ -618,11 +636,15 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if (D->ip_image[ip] != D->ip_image[b]) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "an image block must not span images");
             in_block[ip] = 1;
         }
-        blk_w_off[g] = w_total;
+        // an ordinary image served as a block (no dispersion of its own): block-diagonal weights in compact form (DevProblem::ip_w3),
+        // dense only under the alternative assembly forms, whose kernels read m x m weights
+        const bool compact = e->synthesized_blocks && D->blk_disp_offset[g] < 0 && (assembly_form() == ASSEMBLY_DEFAULT || assembly_form() == ASSEMBLY_NO_FORK);
+        blk_w_off[g] = compact ? -1 : w_total;
         const bool mine = en > b && D->ip_image[b] >= ib && D->ip_image[b] < ie;
         if (mine) {
             const int64_t m = 2 * (int64_t)(en - b);
-            w_total += m * m;
+            if (!compact) w_total += m * m;
+            else e->compact_blocks = true;
             blk_list.push_back(g);
             for (int ip = b; ip < en; ip++) blk_ip_list.push_back(ip);
             e->max_m = std::max(e->max_m, (int)m);
@@ -871,6 +893,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             if (!perm_local.empty() && (rc = upload(e, perm_local.data(), perm_local.size(), &d_perm_local))) return rc;
             for (int g : blk_list) {
                 const int m = 2 * (D->blk_ip_begin[g + 1] - D->blk_ip_begin[g]);
+                if (D->blk_disp_offset[g] < 0 && blk_w_off[g] < 0) continue;      // compact form: filled below for all image points at once
                 if (D->blk_disp_offset[g] < 0) {      // an ordinary image: inv(D) = diag of 2 x 2 blocks in closed form, engine order (PDF:296-319)
                     hipLaunchKernelGGL(fill_diag_weight_kernel, dim3(m), dim3(256), 0, e->stream, p.ip_var_x, p.ip_var_y, p.ip_rho,
                                        D->blk_ip_begin[g], m, d_w + blk_w_off[g]);
@@ -888,6 +911,13 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             e->h_blk_ip_begin.assign(D->blk_ip_begin, D->blk_ip_begin + D->n_image_blocks + 1);
             e->h_blk_mine.assign(D->n_image_blocks, 0);
             for (int g : blk_list) e->h_blk_mine[g] = 1;
+            if (e->compact_blocks) {
+                double *d_w3 = nullptr;
+                if ((rc = dalloc(e, (size_t)3 * D->n_image_points, &d_w3))) return rc;
+                hipLaunchKernelGGL(fill_ip_w3_kernel, dim3((D->n_image_points + 255) / 256), dim3(256), 0, e->stream, p.ip_var_x, p.ip_var_y, p.ip_rho,
+                                   D->n_image_points, d_w3);
+                p.ip_w3 = d_w3;
+            }
             if ((rc = invert_dispersions(e, items))) return rc;
         }
     }
@@ -1852,6 +1882,7 @@ extern "C" int jaicov_neq_get_block_weight(jaicov_engine *e, int32_t block, doub
     const int b = e->h_blk_ip_begin[block], mpts = e->h_blk_ip_begin[block + 1] - b, m = 2 * mpts;
     if (len != (size_t)m * m) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "len must be (2 * points of the block)^2");
     HIPE(e, hipSetDevice(e->device));
+    if (e->h_blk_w_off[block] < 0) FAIL(e, JAICOV_ERR_BAD_ARGUMENT, "this block has no dispersion of its own");
     std::vector<double> w((size_t)m * m);
     HIPE(e, hipMemcpy(w.data(), e->p.blk_w + e->h_blk_w_off[block], w.size() * sizeof(double), hipMemcpyDeviceToHost));
     const int32_t *perm = e->h_perm_local.empty() ? nullptr : e->h_perm_local.data() + b;

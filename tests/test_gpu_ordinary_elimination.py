@@ -220,3 +220,29 @@ def test_two_cameras_with_ordinary_images(oracle_mod):
     assert two.n_image_blocks == 0
     reduced = ec.check_against_oracle(oracle_mod, two)
     assert reduced
+
+
+def test_a_large_ordinary_problem_is_eliminated_with_compact_weights():
+    """The weights of an ordinary image are kept as 2 x 2 blocks (DevProblem::ip_w3), not as an m x m matrix with zeros: 140 images of 2 000
+    points each would need 18 GB in the dense form (which is why such a problem used to fall back to the full-order system) and need
+    6 MB now.  Held against the engine's own full-order path (no oracle at this size): same step, same Omega, and the bits of two builds agree."""
+    fp = scene.make_scene(140, 4000, 2000, dist=scene.DIST_RADIAL, weights="2x2", n_control=6)
+    U, s2 = fp.n_unknowns, fp.sigma2apriori
+    assert fp.n_image_blocks == 0 and 140 * (2 * 2000) ** 2 * 8 > 16 * 2 ** 30
+    eng = engine.Engine(fp)
+    eng.set_parameters(fp.values)
+    eng.build(s2, 0.0)
+    assert eng.reduced_order() == U - 6 * fp.n_images
+    dx = eng.solve(False)
+    om = eng.omega(s2, dx)
+    eng.build(s2, 0.0)
+    assert np.array_equal(eng.solve(False), dx)                            # deterministic assembly: the same bits
+    eng.close()
+    full = engine.Engine(fp, ordinary_group_elimination=-1)                # the full-order system, small-group assembly
+    full.set_parameters(fp.values)
+    full.build(s2, 0.0)
+    assert full.reduced_order() == U
+    dxf = full.solve(False)
+    assert np.abs(dx - dxf).max() <= 1e-9 * np.abs(dxf).max()
+    assert abs(om - full.omega(s2, dxf)) <= 1e-9 * om
+    full.close()
