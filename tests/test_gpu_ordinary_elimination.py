@@ -49,6 +49,17 @@ def test_ordinary_images_are_pre_eliminated(oracle_mod, name, lam):
     np.testing.assert_allclose(Nf[d:, d:], Rf[d:, d:], rtol=0, atol=1e-11 * np.abs(Rf).max())
     np.testing.assert_allclose(n, nref, rtol=0, atol=1e-11 * np.abs(nref).max())
     eng.close()
+    # arrival-order sums (deterministic off): the other instances of the gather with compact block-diagonal weights, both systems
+    arr = engine.Engine(fp, deterministic=False)
+    arr.set_parameters(fp.values)
+    arr.build(s2, lam)
+    assert arr.reduced_order() == U - 6 * fp.n_images
+    np.testing.assert_allclose(arr.solve(False), dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    arr.prepare_inverse(engine.INVERT_FULL)
+    arr.build(s2, lam)
+    Na, na = arr.get_normal()
+    np.testing.assert_allclose(packed_to_full(Na, U)[d:, d:], Rf[d:, d:], rtol=0, atol=1e-11 * np.abs(Rf).max())
+    arr.close()
     # the old path (ordinary groups one by one into the full-order system) stays available and agrees
     old = engine.Engine(fp, ordinary_group_elimination=-1)
     old.set_parameters(fp.values)
