@@ -997,9 +997,10 @@ hipError_t DenseSolver::flow_init() {
     // binds at small orders; the path potrf(c-1) -> inverse -> product with the inverse -> last update of tile (c+1, c) was (the chain
     // waited 6-9 us per block column for that tile at order 3 072), and that is the path this workgroup shortens: order 3 072
     // 1.70 -> 1.58 ms.  At order 8 192 it is neutral (5.3 vs 5.4 ms) and at 15 104 it changes nothing (22.7 vs 22.8 ms: the tiles it
-    // needs are late by the same path one diagonal further out, and the row chain of the tile kernel binds), so it is used below
-    // 48 block columns only.  JAICOV_FACTOR_FORM=chain2 / chain3 (test hooks): the chain form with two / three workgroups at any order.
-    flow_second = flow_chain && factor_form() != FACTOR_CHAIN2 && (nb < 48 || factor_form() == FACTOR_CHAIN3) ? 2 : 0;
+    // needs are late by the same path one diagonal further out, and the row chain of the tile kernel binds).  Crossover measured at the end of
+    // round 4 (ms, two / three chain workgroups): 40 block columns 2.88 / 2.65, 48: 3.60 / 3.39, 56: 4.42 / 4.20, 64: 5.36 / 5.21, 72: 6.65 / 6.53,
+    // 80: 8.25 / 8.21, 118: 22.3 / 22.7 -> used below 80 block columns.  JAICOV_FACTOR_FORM=chain2 / chain3 (test hooks): the chain form with two / three workgroups at any order.
+    flow_second = flow_chain && factor_form() != FACTOR_CHAIN2 && (nb < 80 || factor_form() == FACTOR_CHAIN3) ? 2 : 0;
     const std::vector<int4> tasks = flow_schedule(nb, row_blocks, 1, flow_chain, flow_second);
     flow_tasks = (int)tasks.size();
     flow_task_host = tasks;

@@ -908,7 +908,7 @@ int factor_form() {
     if (!strcmp(e, "two_step")) return FACTOR_TWO_STEP;
     if (!strcmp(e, "one_kernel")) return FACTOR_ONE_KERNEL;
     if (!strcmp(e, "chain2")) return FACTOR_CHAIN2;          // the chain form with two chain workgroups (no third one for the second subdiagonal)
-    if (!strcmp(e, "chain3")) return FACTOR_CHAIN3;          // ... with three, whatever the order (default: below 48 block columns)
+    if (!strcmp(e, "chain3")) return FACTOR_CHAIN3;          // ... with three, whatever the order (default: below 80 block columns)
     return FACTOR_DEFAULT;
 }
 

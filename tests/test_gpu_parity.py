@@ -107,6 +107,21 @@ def test_factor_tile_by_tile(n, form, monkeypatch):
     np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize("n", [6400, 10112])
+def test_factor_tile_by_tile_at_the_orders_between(n):
+    """50 block columns: the chain form with its third workgroup (default below 80 block columns since round 4's last sweep); 79: the largest
+    order that runs so.  Held tile by tile against LAPACK like the small orders above."""
+    import ctypes as C
+    lib = engine.load_library()
+    lib.jaicov_debug_potrf_factor.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(n)
+    G = rng.normal(size=(n, 64))
+    S = np.ascontiguousarray(G @ G.T / 64 + np.diag(1.0 + rng.random(n)))
+    out = np.zeros((n, n))
+    assert lib.jaicov_debug_potrf_factor(n, S.ctypes.data, out.ctypes.data) == 0
+    np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-11)
+
+
 def test_dense_not_spd_reports_singular():
     S = -np.eye(130)
     with pytest.raises(engine.EngineError) as ei:

@@ -41,7 +41,7 @@ def test_no_factorisation_is_abandoned_over_many_passes(cfg4_scene):
 
 def test_no_factorisation_is_abandoned_at_config3_size():
     """The same at config 3 (order 3 014 after the elimination of the ordinary images' EO: 24 block columns), where the chain form runs
-    with its THIRD workgroup (round 4: below 48 block columns) and the chain, not the tile kernel, sets the pace: 400 passes by default,
+    with its THIRD workgroup (round 4: below 80 block columns) and the chain, not the tile kernel, sets the pace: 400 passes by default,
     JAICOV_SOAK_PASSES for more."""
     from bundle_adjustment_amd import scene
     fp = scene.config("cfg3")
