@@ -63,6 +63,14 @@ namespace jaicov {
 // control words
 enum { FLOW_TICKET = 0, FLOW_ABORT = 1, FLOW_DIAG_NEXT = 2, FLOW_CHAIN_AT = 3, FLOW_STALE = 4, FLOW_STALE_CONFIRMED = 5, FLOW_RESCUED = 6, FLOW_WG_OFF = 7, FLOW_CTRL_WORDS = 16 };   // RESCUED: hits of the read-modify-write poll after > 1 ms of waiting   // CHAIN_AT: column << 4 | stage of the chain workgroup
 constexpr int FLOW_FIN = 1 << 20;        // task.w = k1 | FLOW_FIN: finish the tile after the updates
+// Split update ranges (the late block columns' tiles: each has ~100 block-column steps to do one after the other, is drawn late -- tickets go
+// out in column order -- and the chip drains while the last of them crawl through their ranges).  task.w | FLOW_PART: a PARTIAL-SUM task: zeros
+// instead of the tile, the block columns [k0, k1) subtracted, the sum stored to partial buffer (task.z >> 12) and its flag set.  The tile's
+// own task takes the LAST piece of the range, then adds the (task.w >> 22 & 7) partial sums of buffers (task.z >> 12) ... in buffer order
+// (a fixed order: same bits in every run) before it stores / finishes the tile.  k0 = task.z & 4095.
+constexpr int FLOW_PART = 1 << 21;
+constexpr int FLOW_NPART_SHIFT = 22;
+constexpr int FLOW_BUF_SHIFT = 12;
 constexpr int FLOW_LDS = 144;            // LDS row stride of both operands (gemm_f64.h: == 16 mod 32 doubles)
 constexpr int FLOW_STAGE = GEMM_BK * 2 * FLOW_LDS;
 
@@ -92,6 +100,8 @@ struct FlowArgs {
     double *diag_scratch;    // INLINE_DIAG: [grid][128 x DP + 8 x 16 x WDP] work arrays of potrf_diag_body in global memory
     const double *zeros;     // 64 zeros
     double *scratch;         // [grid][128 x 128] per workgroup: operand of the multiplication by inv(L_jj)'
+    double *partial;         // [partial buffers][128 x 128] partial sums of split update ranges (FLOW_PART)
+    int *pflag;              // [partial buffers] the partial sum is in memory
     long long timeout;       // wall-clock ticks (100 MHz) a wait may take before the factorisation is abandoned
     int fake_a;              // timing experiment (wrong results): every tile reads row block j's strip as its A operand too
     int crit_prio;           // s_setprio level of the tasks on the critical chain; 0 = none
@@ -187,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
     __shared__ double smem[2 * FLOW_STAGE];
     __shared__ int s_msg[4];
     const int tid = threadIdx.x;
+    const int bid = (int)blockIdx.x;
     // Everything derived from the thread index is recomputed where it is used, from a copy of tid the compiler cannot see
     // through: hoisted out of the persistent loop those values (dozens of them) stay live across the MFMA loop, the kernel
     // spills, and a kernel with a scratch segment is admitted with fewer waves per shader engine (measured: 458 of the 496
@@ -230,18 +241,26 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             sb[32 * q + FLOW_LDS - odd] = rb[S][q].y;                                                        \
         }                                                                                                    \
     } while (0)
-#define FLOW_MFMA(STAGE)                                                                                     \
+#define FLOW_FRAG(STAGE, KS, A_, B_)                                                                         \
     do {                                                                                                     \
         const double *sa = smem + (STAGE) * FLOW_STAGE + fa;                                                 \
         const double *sb = smem + (STAGE) * FLOW_STAGE + GEMM_BK * FLOW_LDS + fb;                            \
+        const int sh = 8 * ((KS) & 1) + 4 * ((KS) >> 1);                                                     \
+        _Pragma("unroll") for (int x = 0; x < 4; x++) A_[x] = sa[(4 * (KS)) * FLOW_LDS + 16 * x + sh];       \
+        _Pragma("unroll") for (int y = 0; y < 4; y++) B_[y] = sb[(4 * (KS)) * FLOW_LDS + 16 * y + sh];       \
+    } while (0)
+#define FLOW_MM(A_, B_)                                                                                      \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int x = 0; x < 4; x++)                                                        \
+            _Pragma("unroll") for (int y = 0; y < 4; y++)                                                    \
+                acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(A_[x], B_[y], acc[x][y], 0, 0, 0);          \
+    } while (0)
+#define FLOW_MFMA(STAGE)                                                                                     \
+    do {                                                                                                     \
         _Pragma("unroll") for (int ks = 0; ks < 4; ks++) {                                                   \
             double a[4], b[4];                                                                               \
-            const int sh = 8 * (ks & 1) + 4 * (ks >> 1);                                                     \
-            _Pragma("unroll") for (int x = 0; x < 4; x++) a[x] = sa[(4 * ks) * FLOW_LDS + 16 * x + sh];      \
-            _Pragma("unroll") for (int y = 0; y < 4; y++) b[y] = sb[(4 * ks) * FLOW_LDS + 16 * y + sh];      \
-            _Pragma("unroll") for (int x = 0; x < 4; x++)                                                    \
-                _Pragma("unroll") for (int y = 0; y < 4; y++)                                                \
-                    acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[x], b[y], acc[x][y], 0, 0, 0);        \
+            FLOW_FRAG(STAGE, ks, a, b);                                                                      \
+            FLOW_MM(a, b);                                                                                   \
         }                                                                                                    \
     } while (0)
         // nk is a multiple of 8.  The loads are issued unconditionally (the last two of a run re-read the last step): behind
@@ -280,6 +299,8 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
 #undef FLOW_GLOAD
 #undef FLOW_LSTORE
 #undef FLOW_MFMA
+#undef FLOW_FRAG
+#undef FLOW_MM
     };
 
     // The workgroups dispatched last on an XCD that hosts a chain workgroup take no tickets.  Those XCDs hold fewer tile
@@ -300,8 +321,11 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
         __syncthreads();
         if (t >= g.n_tasks) break;
         const int4 tk = g.tasks[t];
-        const int ti = tk.x, tj = tk.y, k0 = tk.z, k1 = tk.w & (FLOW_FIN - 1);
-#define FLOW_STAGE_MARK(kk, st) do { if (tid == 0) flow_st(g.wgstate + blockIdx.x, (t << 12) | ((kk) << 4) | (st)); } while (0)
+        const int ti = tk.x, tj = tk.y, k0 = tk.z & ((1 << FLOW_BUF_SHIFT) - 1), k1 = tk.w & (FLOW_FIN - 1);
+        const int pbuf = tk.z >> FLOW_BUF_SHIFT, npart = (tk.w >> FLOW_NPART_SHIFT) & 7;
+        const bool part = (tk.w & FLOW_PART) != 0;
+        const bool first_visit = k0 == 0 || npart > 0;     // the tile has not been stored by an earlier visit
+#define FLOW_STAGE_MARK(kk, st) do { if (tid == 0) flow_st(g.wgstate + bid, (t << 12) | ((kk) << 4) | (st)); } while (0)
         FLOW_STAGE_MARK(k0, 1);
         const bool fin = (tk.w & FLOW_FIN) != 0;
         long long waited = 0, t_start = 0, t_c = 0, t_upd = 0, c_c = 0, c_upd = 0, w_upd = 0;
@@ -319,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
         int k = k0;
         for (int phase = 0;; phase++) {
             // -- what has to be there before the accumulators are loaded
-            if ((phase == 0 && k0 > 0) || phase == 1) {
+            if ((phase == 0 && !first_visit && !part) || phase == 1) {
                 FLOW_STAGE_MARK(k, 2);
                 if (tid == 0) {
                     // phase 0: an earlier (partial) visit wrote the tile; phase 1: inv(L_jj) from the diagonal kernel
@@ -338,11 +362,11 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                 FLOW_OPAQUE_TID(tq);
                 const long trow = 64 * (tq >> 7) + ((tq & 63) >> 4), tcol = 64 * ((tq >> 6) & 1) + (tq & 15);
                 // phase 1 starts from zeros: read like a tile (row stride 0) so that there is one load site
-                const bool scaled = phase == 0 && k0 == 0 && g.src != nullptr && ti < g.nb;   // first load of a matrix tile from N
-                const double *src = phase != 0 ? g.zeros + (tq & 15)
+                const bool scaled = phase == 0 && first_visit && !part && g.src != nullptr && ti < g.nb;   // first load of a matrix tile from N
+                const double *src = phase != 0 || part ? g.zeros + (tq & 15)
                                     : scaled   ? g.src + ((long)ti * 128 + trow) * g.src_ld + (long)tj * 128 + tcol
                                                : g.L + ((long)ti * 128 + trow) * g.ld + (long)tj * 128 + tcol;
-                const long sld = phase != 0 ? 0 : (scaled ? g.src_ld : g.ld);
+                const long sld = phase != 0 || part ? 0 : (scaled ? g.src_ld : g.ld);
 #pragma unroll
                 for (int x = 0; x < 4; x++)
 #pragma unroll
@@ -446,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                     asign = -1.0;             // C -= L[i][k] L[j][k]'
                     k += cnt;
                 } else {
-                    Ap = g.scratch + (long)blockIdx.x * 16384;
+                    Ap = g.scratch + (long)bid * 16384;
                     Bp = g.invd + (long)tj * 16384;
                     lda = ldb = 128;
                     nk = 8;
@@ -456,6 +480,31 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                 accumulate(Ap, lda, Bp, ldb, nk, asign);
             }
             if (!ok) break;
+            // -- the partial sums of the other pieces of a split range (written by earlier tickets), in buffer order
+            if (phase == 0 && npart > 0) {
+                for (int q = 0; q < npart; q++) {
+                    FLOW_STAGE_MARK(k, 9);
+                    if (tid == 0) {
+                        const bool r = flow_spin(g.pflag + pbuf + q, 1, g.ctrl, g.timeout, &waited);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        drain_stores();
+                        s_msg[1] = r ? 1 : 0;
+                    }
+                    __syncthreads();
+                    ok = s_msg[1] != 0;
+                    __syncthreads();
+                    if (!ok) break;
+                    FLOW_OPAQUE_TID(tq);
+                    const double *pp = g.partial + (long)(pbuf + q) * 16384 + (64 * (tq >> 7) + ((tq & 63) >> 4)) * 128 + 64 * ((tq >> 6) & 1) + (tq & 15);
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+#pragma unroll
+                            for (int y = 0; y < 4; y++) acc[x][y][r] += pp[(16 * x + 4 * r) * 128 + 16 * y];
+                }
+                if (!ok) break;
+            }
             if (g.trace && phase == 0) { t_upd = wall_clock64(); c_upd = clock64(); w_upd = waited; }
             // -- where the accumulators go, and which flag tells whom
             FLOW_STAGE_MARK(k, 5 + phase);
@@ -463,9 +512,10 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             {
                 FLOW_OPAQUE_TID(tq);
                 const long trow = 64 * (tq >> 7) + ((tq & 63) >> 4), tcol = 64 * ((tq >> 6) & 1) + (tq & 15);
-                double *dst = to_scratch ? g.scratch + (long)blockIdx.x * 16384 + trow * 128 + tcol
-                                         : g.L + ((long)ti * 128 + trow) * g.ld + (long)tj * 128 + tcol;
-                const long dld = to_scratch ? 128 : g.ld;
+                double *dst = part         ? g.partial + (long)pbuf * 16384 + trow * 128 + tcol
+                              : to_scratch ? g.scratch + (long)bid * 16384 + trow * 128 + tcol
+                                           : g.L + ((long)ti * 128 + trow) * g.ld + (long)tj * 128 + tcol;
+                const long dld = part || to_scratch ? 128 : g.ld;
 #pragma unroll
                 for (int x = 0; x < 4; x++)
 #pragma unroll
@@ -486,7 +536,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                     drain_stores();
                 }
                 __syncthreads();
-                double *ws = g.diag_scratch + (long)blockIdx.x * (128 * DP + 8 * 16 * WDP);
+                double *ws = g.diag_scratch + (long)bid * (128 * DP + 8 * 16 * WDP);
                 flow_inline_diag(g.L + (long)tj * 128 * g.ld + (long)tj * 128, g.ld, g.invd + (long)tj * 16384, g.info, tj, ws);
                 drain_stores();
                 __syncthreads();
@@ -498,7 +548,8 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
                 break;
             }
             if (tid == 0) {
-                if (phase == 1) flow_st(g.done + (long)ti * g.fs + tj, 1);                 // L[i][j] is final
+                if (part) flow_st(g.pflag + pbuf, 1);                                      // a partial sum, for the tile's own task
+                else if (phase == 1) flow_st(g.done + (long)ti * g.fs + tj, 1);            // L[i][j] is final
                 else if (fin) flow_st(g.diag_ready + tj, 1);                               // updated diagonal tile, for the diagonal kernel
                 else flow_st(g.applied + (long)ti * g.fs + tj, k1 + 1);                    // partial visit (chain form: the tile is the chain workgroup's from here)
             }
@@ -511,7 +562,7 @@ __global__ __launch_bounds__(256, 2) void chol_tile_kernel(FlowArgs g) {
             long long *tr = g.trace + 8 * (long)t;
             tr[0] = t_start; tr[1] = t_c; tr[2] = t_upd; tr[3] = wall_clock64(); tr[4] = waited;
             tr[5] = c_upd - c_c;   // shader-clock cycles of the update phase (against tr[2] - tr[1] at 100 MHz: the clock it ran at)
-            tr[6] = (long long)blockIdx.x | ((long long)n_runs << 16) | (w_upd << 32);   // block, runs, ticks waited before the updates were done
+            tr[6] = (long long)bid | ((long long)n_runs << 16) | (w_upd << 32);   // block, runs, ticks waited before the updates were done
             tr[7] = (long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |                              // HW_ID
                     ((long long)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf) << 32);   // XCC_ID
         }
@@ -907,16 +958,41 @@ __global__ __launch_bounds__(256) void potrf_chain_kernel(FlowArgs g) {
     }
 }
 
+// Which tasks get their update range split (flow_schedule).  Round 5.  Tickets go out in column order, so the tiles of the late block columns --
+// each with ~100 block-column steps to do one after the other, 3+ ms -- are drawn last; the chip drained while they crawled through their
+// ranges (mean resident tasks in the last two tenths of the span: 417 and 138 of 496), and the chain waited for exactly those tiles.  Cutting
+// the range in two, the first half as an independent partial-sum task at the head of the column (its operands are final long before: it never
+// waits, 30.2 us per step), halves the serial length of every late task.  Measured (ms per factorisation, without / with, same box):
+// 80 block columns 8.33 / 8.18, 100: 14.4 / 13.8, 118: 22.5 / 21.4, 142: 36.7 / 35.5; 64: 5.20 / 5.40, 40: 2.63 / 2.80 (the partial sums' extra
+// store + load and the later start of the column's own tasks cost more than the shorter tail saves).  At 118 block columns the first split
+// column anywhere in 40 .. 72 gives the same time (21.35-21.45), 88: 21.8; three pieces 22.3, four 23.3 (worse than none: the tile's own task
+// then spends most of its life waiting for operand columns, holding a slot).  JAICOV_FLOW_SPLIT="m:from" is a test hook.
+void flow_split_rule(int nb, int *m, int *from) {
+    *m = 1; *from = 1 << 30;
+    if (nb >= 80) { *m = 2; *from = nb / 2; }
+    if (const char *e = getenv("JAICOV_FLOW_SPLIT")) {
+        int a = 1, b = 0;
+        if (sscanf(e, "%d:%d", &a, &b) >= 1) { *m = a < 1 ? 1 : a; *from = b; }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Task list: left-looking.  w = 1: column-major; column j: the diagonal tile first, then the tiles below it (the tile right
 // below feeds the next diagonal tile: it is the one the chain waits for), the right-hand-side rows last.  w > 1: groups of w
 // columns; the tiles of the group's diagonal blocks first, then row by row the w tiles of a row, which stream the same A
 // strip L[i][0..j) at the same time (the second reader finds it in L2 / the Infinity Cache).  Either way a tile only depends
 // on tiles that come earlier in the list.
-static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain, int second) {
+// split_m > 1: the update range of every task of the block columns >= split_from is cut into split_m pieces (when each piece still
+// has >= 8 block columns); the first split_m - 1 become partial-sum tasks (FLOW_PART) at the HEAD of their column's tasks -- their
+// operands are tiles of much earlier columns, so they run at once and in parallel with each other --, the tile's own task keeps the last
+// piece and adds the sums.  *n_bufs = partial buffers needed.
+static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain, int second, int split_m = 1, int split_from = 1 << 30, int *n_bufs = nullptr) {
     std::vector<int4> tasks;
     tasks.reserve((size_t)nb * (row_blocks + 1) / 2 + row_blocks);
     if (w < 1) w = 1;
+    if (split_m > 8) split_m = 8;
+    if (w > 1) split_m = 1;
+    int bufs = 0;
     // chain form (potrf_chain_kernel): the diagonal tile (j, j) is visited for the block columns < j - 1 only and the tile below
     // it, (j + 1, j), is not finished: the chain workgroup takes both from there.  With the optional third workgroup
     // (`second` = 1 / 2) the tile (j + 2, j) is not finished either, and (2) the tile (j + 1, j) lacks its last update.
@@ -926,27 +1002,54 @@ static std::vector<int4> flow_schedule(int nb, int row_blocks, int w, bool chain
         if (chain && second >= 1 && i == j + 2 && i < nb) return make_int4(i, j, 0, j);     // all updates; workgroup 2 finishes it
         return make_int4(i, j, 0, j | FLOW_FIN);
     };
+    std::vector<std::vector<int4>> head(nb), own(nb);      // per block column: partial-sum tasks emitted at its head, its tiles' own tasks
     for (int j0 = 0; j0 < nb; j0 += w) {
         const int j1 = std::min(nb, j0 + w);
+        auto add = [&](int i, int j) {
+            int4 t = task(i, j);
+            const int k1 = t.w & (FLOW_FIN - 1);
+            if (split_m > 1 && j >= split_from && k1 >= 8 * split_m) {
+                int a = 0;
+                for (int q = 1; q < split_m; q++) {
+                    const int c = (int)((long)k1 * q / split_m);
+                    head[j].push_back(make_int4(i, j, a | ((bufs + q - 1) << FLOW_BUF_SHIFT), c | FLOW_PART));
+                    a = c;
+                }
+                t.z = a | (bufs << FLOW_BUF_SHIFT);
+                t.w |= (split_m - 1) << FLOW_NPART_SHIFT;
+                bufs += split_m - 1;
+            }
+            own[j0].push_back(t);
+        };
         for (int j = j0; j < j1; j++)
-            for (int i = j; i < j1; i++) tasks.push_back(task(i, j));
+            for (int i = j; i < j1; i++) add(i, j);
         for (int i = j1; i < row_blocks; i++)
-            for (int j = j0; j < j1; j++) tasks.push_back(task(i, j));
+            for (int j = j0; j < j1; j++) add(i, j);
     }
+    for (int j = 0; j < nb; j++) {
+        tasks.insert(tasks.end(), head[j].begin(), head[j].end());
+        tasks.insert(tasks.end(), own[j].begin(), own[j].end());
+    }
+    if (n_bufs) *n_bufs = bufs;
     return tasks;
 }
 
 }  // namespace jaicov
 // debug / tests (no device needed): the task list of the dataflow factorisation, 4 ints per task {i, j, k0, k1 | FIN << 20};
 // returns the number of tasks (the first `cap` are written)
-extern "C" int jaicov_debug_flow_tasks(int nb, int row_blocks, int w, int chain, int second, int *out, int cap) {
+extern "C" int jaicov_debug_flow_tasks2(int nb, int row_blocks, int w, int chain, int second, int split_m, int split_from, int *out, int cap) {
     if (nb < 1 || row_blocks < nb) return -1;
-    const std::vector<int4> t = jaicov::flow_schedule(nb, row_blocks, w, chain != 0, second);
+    const std::vector<int4> t = jaicov::flow_schedule(nb, row_blocks, w, chain != 0, second, split_m, split_from);
     for (size_t q = 0; q < t.size() && (int)q < cap; q++) {
         out[4 * q] = t[q].x; out[4 * q + 1] = t[q].y; out[4 * q + 2] = t[q].z; out[4 * q + 3] = t[q].w;
     }
     return (int)t.size();
 }
+extern "C" int jaicov_debug_flow_tasks(int nb, int row_blocks, int w, int chain, int second, int *out, int cap) {
+    return jaicov_debug_flow_tasks2(nb, row_blocks, w, chain, second, 1, 1 << 30, out, cap);
+}
+// the split the solver uses for nb block columns: *m pieces for the tasks of the block columns >= *from (m = 1: none)
+extern "C" void jaicov_debug_flow_split(int nb, int *m, int *from) { jaicov::flow_split_rule(nb, m, from); }
 namespace jaicov {
 
 // Can two kernels of this process run at the same time?  Probed once: a kernel that waits (at most 50 ms) for a word that a
@@ -1001,13 +1104,16 @@ hipError_t DenseSolver::flow_init() {
     // round 4 (ms, two / three chain workgroups): 40 block columns 2.88 / 2.65, 48: 3.60 / 3.39, 56: 4.42 / 4.20, 64: 5.36 / 5.21, 72: 6.65 / 6.53,
     // 80: 8.25 / 8.21, 118: 22.3 / 22.7 -> used below 80 block columns.  JAICOV_FACTOR_FORM=chain2 / chain3 (test hooks): the chain form with two / three workgroups at any order.
     flow_second = flow_chain && factor_form() != FACTOR_CHAIN2 && (nb < 80 || factor_form() == FACTOR_CHAIN3) ? 2 : 0;
-    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, 1, flow_chain, flow_second);
+    int split_m = 1, split_from = 1 << 30;
+    flow_split_rule(nb, &split_m, &split_from);
+    flow_partials = 0;
+    const std::vector<int4> tasks = flow_schedule(nb, row_blocks, 1, flow_chain, flow_second, split_m, split_from, &flow_partials);
     flow_tasks = (int)tasks.size();
     flow_task_host = tasks;
     HIPCHK(hipMalloc(&flow_task_list, tasks.size() * sizeof(int4)));
     HIPCHK(hipMemcpy(flow_task_list, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice));
     flow_fs = nb;
-    flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + 2 * nb + 2048;   // ... + one state word per workgroup, and room for their copy at the moment a wait runs out
+    flow_words = (size_t)FLOW_CTRL_WORDS + 2 * (size_t)row_blocks * nb + 2 * nb + 2048 + (size_t)flow_partials;   // ... + one state word per workgroup, and room for their copy at the moment a wait runs out
     // The flags live in FINE-GRAINED device memory (coherent across the XCDs while a kernel runs): in ordinary (coarse-grained)
     // memory polls of every flavour -- sc1, system scope, read-modify-write, with an acquire in between -- were seen to miss
     // flags that memory held as set, about once in 1 000-2 400 factorisations ("Visibility").
@@ -1027,6 +1133,7 @@ hipError_t DenseSolver::flow_init() {
     if (flow_grid > 1024) flow_grid = 1024;
     HIPCHK(hipMalloc(&flow_scratch, ((size_t)flow_grid * 16384 + 64) * sizeof(double)));
     HIPCHK(hipMemset(flow_scratch + (size_t)flow_grid * 16384, 0, 64 * sizeof(double)));
+    if (flow_partials > 0) HIPCHK(hipMalloc(&flow_partial, (size_t)flow_partials * 16384 * sizeof(double)));
     HIPCHK(hipHostMalloc((void **)&flow_alive, 4 * sizeof(int), hipHostMallocMapped));
     flow_alive[0] = flow_alive[1] = flow_alive[2] = flow_alive[3] = 0;
     HIPCHK(hipEventCreateWithFlags(&flow_e0, hipEventDisableTiming));
@@ -1042,6 +1149,8 @@ void DenseSolver::flow_release() {
     if (flow_task_list) hipFree(flow_task_list);
     if (flow_flags) hipFree(flow_flags);
     if (flow_scratch) hipFree(flow_scratch);
+    if (flow_partial) hipFree(flow_partial);
+    flow_partial = nullptr;
     if (flow_trace) hipFree(flow_trace);
     if (flow_diag_scratch) hipFree(flow_diag_scratch);
     flow_diag_scratch = nullptr;
@@ -1065,6 +1174,8 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.diag_ready = g.applied + (size_t)row_blocks * nb;
     g.factored = g.diag_ready + nb;
     g.wgstate = g.factored + nb;
+    g.pflag = g.wgstate + 2048;
+    g.partial = flow_partial;
     g.info = d_info;
     g.scratch = flow_scratch;
     g.zeros = flow_scratch + (size_t)flow_grid * 16384;

@@ -17,6 +17,7 @@ struct GemmArgs;
 constexpr int DENSE_NB = 128;      // diagonal block handled by one workgroup in LDS
 constexpr int DENSE_MAX_RHS = 8;   // rhs vectors the substitution kernels carry at once
 enum { FACTOR_DEFAULT = 0, FACTOR_STREAMS = 1, FACTOR_TWO_STEP = 2, FACTOR_ONE_KERNEL = 3, FACTOR_CHAIN2 = 4, FACTOR_CHAIN3 = 5 };
+void flow_split_rule(int nb, int *m, int *from);   // cholflow.hip
 int factor_form();                 // JAICOV_FACTOR_FORM (dense.hip): test hook for the non-default forms of the factorisation
 
 // Streams are kept for the life of the process (dense.hip): creating one costs 12-35 ms on this stack (a hardware queue is set up), destroying
@@ -81,6 +82,8 @@ struct DenseSolver {
     int *flow_flags = nullptr;           // control words, done / applied flags, diag_ready
     size_t flow_words = 0;
     double *flow_scratch = nullptr;
+    double *flow_partial = nullptr;      // partial sums of split update ranges (cholflow.hip, FLOW_PART)
+    int flow_partials = 0;               // ... how many 128 x 128 buffers
     long long *flow_trace = nullptr;
     double *flow_diag_scratch = nullptr; // one-kernel form (kernels cannot overlap on this host): work arrays of the inline diagonal blocks
     bool flow_kernels_overlap();         // probed once per process

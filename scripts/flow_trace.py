@@ -32,14 +32,30 @@ if want_trace and nt.value:
                   f" + load/solve {(cu[:, 3] - cu[:, 2])[sl].mean():.1f} + update {(cu[:, 4] - cu[:, 3])[sl].mean():.1f}"
                   f"   [potrf: factor {(cu[:, 7] - cu[:, 0])[sl].mean():.1f}, store issue {(cu[:, 1] - cu[:, 7])[sl].mean():.1f}; load/solve: loads+drain {(cu[:, 5] - cu[:, 2])[sl].mean():.1f}, products {(cu[:, 6] - cu[:, 5])[sl].mean():.1f}, store issue {(cu[:, 3] - cu[:, 6])[sl].mean():.1f}]")
         print("chain: potrf start of every 8th column (us):", np.round(cu[::8, 0]).astype(int))
-    t = tr[: nt.value * 8].reshape(-1, 8)
-    t0 = t[:, 0].min()
+    t_all = tr[: nt.value * 8].reshape(-1, 8)
+    # the task list the solver ran (split update ranges: partial-sum tasks sit between the tiles' own tasks, which stay column-major)
+    sm, sf = C.c_int(1), C.c_int(0)
+    L.jaicov_debug_flow_split(nb, C.byref(sm), C.byref(sf))
+    form = os.environ.get("JAICOV_FACTOR_FORM", "")
+    second = 2 if (form == "chain3" or (form != "chain2" and nb < 80)) else 0
+    tl = np.zeros((nt.value, 4), np.int32)
+    L.jaicov_debug_flow_tasks2.argtypes = [C.c_int] * 7 + [C.c_void_p, C.c_int]
+    ntl = L.jaicov_debug_flow_tasks2(nb, nb + 1, 1, 1, second, sm.value, sf.value, tl.ctypes.data, nt.value)
+    is_part = (tl[:, 3] & (1 << 21)) != 0 if ntl == nt.value else np.zeros(nt.value, bool)
+    if is_part.any():
+        pt = t_all[is_part]
+        pus = (pt[:, :4] - t_all[:, 0].min()) / 100.0
+        psteps = (tl[is_part, 3] & 0xfff) - (tl[is_part, 2] & 0xfff)
+        print(f"split update ranges: {sm.value} pieces from block column {sf.value}: {int(is_part.sum())} partial-sum tasks, {psteps.mean():.1f} steps each, "
+              f"{((pus[:, 2] - pus[:, 1]) / psteps).mean():.2f} us per step, waiting {pt[:, 4].mean() / 100.0:.1f} us per task; first starts at {pus[:, 0].min():.0f} us, last ends at {pus[:, 3].max():.0f} us")
+    t = t_all[~is_part]
+    t0 = t_all[:, 0].min()
     us = (t[:, :4] - t0) / 100.0
     wait = t[:, 4] / 100.0
     span = us[:, 3].max()
-    busy = (us[:, 3] - us[:, 0]).sum()
-    slots = len(np.unique(t[:, 6] & 0xffff))
-    print(f"span {span:.0f} us, workgroups seen {slots}, sum of task time {busy / slots:.0f} us per workgroup, of which waiting {wait.sum() / slots:.0f} us")
+    busy = ((t_all[:, 3] - t_all[:, 0]) / 100.0).sum()
+    slots = len(np.unique(t_all[:, 6] & 0xffff))
+    print(f"span {span:.0f} us, workgroups seen {slots}, sum of task time {busy / slots:.0f} us per workgroup, of which waiting {t_all[:, 4].sum() / 100.0 / slots:.0f} us")
     # tasks are column-major: find the diagonal tasks = first task of each column
     idx = 0
     col_end = []
@@ -52,7 +68,8 @@ if want_trace and nt.value:
     print("column completion (us) every 8th:", np.round(col_end[::8]).astype(int))
     print(f"per-column advance: first 16 mean {d[:16].mean():.1f} us, middle mean {d[nb // 2 - 8: nb // 2 + 8].mean():.1f}, last 16 mean {d[-16:].mean():.1f}")
     q = np.linspace(0, span, 11)
-    act = [(np.minimum(us[:, 3], b) - np.maximum(us[:, 0], a)).clip(0).sum() / (b - a) for a, b in zip(q[:-1], q[1:])]
+    us_all = (t_all[:, :4] - t0) / 100.0
+    act = [(np.minimum(us_all[:, 3], b) - np.maximum(us_all[:, 0], a)).clip(0).sum() / (b - a) for a, b in zip(q[:-1], q[1:])]
     wt = []
     print("mean resident tasks per tenth of the span:", np.round(act, 0))
     # which CUs ran the workgroups (HW_ID: cu 11:8, sh 12, se 15:13; XCC id separately)
@@ -98,7 +115,8 @@ if want_trace and nt.value:
             m2 = offd & (d_ij >= lo) & (d_ij < hi)
             if m2.any():
                 print(f"   rows j+{lo}..j+{hi - 1}: waiting during updates {w_upd[m2].mean():.0f} us, runs {runs[m2].mean():.1f}, start lag {lag_s[m2].mean():.0f} us")
-        print(f"update phase per block column, tiles of columns 41-79: {(upd_us[mid] / ks[mid]).mean():.2f} us incl. waits ({(wait[mid] / ks[mid]).mean():.2f} us waiting)")
+        steps = np.maximum(((tl[~is_part, 3] & 0xfff) - (tl[~is_part, 2] & 0xfff)) if ntl == nt.value else ks, 1)
+        print(f"update phase per block column, tiles of columns 41-79: {(upd_us[mid] / steps[mid]).mean():.2f} us incl. waits ({(wait[mid] / steps[mid]).mean():.2f} us waiting)")
         # chain: (j,j) handed to the diagonal kernel -> L[j+1][j] final -> (j+1,j+1) handed over
         starts = np.cumsum([0] + [nb + 1 - j for j in range(nb)])
         a = np.array([us[starts[j], 3] for j in range(nb - 1)])
@@ -121,3 +139,14 @@ if want_trace and nt.value:
         print("latest first task starts (workgroup, us after the first, xcc, se, cu):", [(b, round((v[0] - t0) / 100.0), v[1], (v[2] >> 13) & 7, (v[2] >> 8) & 0xf) for b, v in late])
         for x in (0, 1):
             print(f"xcc {x}: workgroups", sorted(b for b, v in first.items() if v[1] == x))
+    if os.environ.get("FLOW_TRACE_PATH") and ct[:, 0].any():
+        # the dependency path into the chain workgroup's wait, column by column: when did potrf(c) end, when were the finished tiles of block column c - 1
+        # that the two tiles need there, when were the two tiles' updates done and stored
+        tix = {(int(a), int(b)): q for q, (a, b) in enumerate(zip(rowi, ks))}
+        lo, hi = [int(v) for v in os.environ["FLOW_TRACE_PATH"].split(":")]
+        print("c: potrf(c) start, end | tile (c+1,c-1): updates done, final | tile (c+1,c): start, C loaded, updates done, stored, runs, waited | diag (c+1,c+1): stored | chain: operands there, solve done, update done   [us after potrf(c) start]")
+        cu = (ct[:, :8] - t0) / 100.0      # same origin as the tasks
+        for c in range(lo, hi):
+            z = cu[c, 0]
+            a = tix.get((c + 1, c - 1)); b = tix[(c + 1, c)]; d = tix[(c + 1, c + 1)]
+            print(f"{c}: 0 {cu[c, 1] - z:.0f} | {us[a, 2] - z:.0f} {us[a, 3] - z:.0f} | {us[b, 0] - z:.0f} {us[b, 1] - z:.0f} {us[b, 2] - z:.0f} {us[b, 3] - z:.0f} runs {runs[b]} waited {wait[b]:.0f} | {us[d, 3] - z:.0f} | {cu[c, 2] - z:.0f} {cu[c, 3] - z:.0f} {cu[c, 4] - z:.0f}")

@@ -107,10 +107,34 @@ def test_factor_tile_by_tile(n, form, monkeypatch):
     np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-12)
 
 
-@pytest.mark.parametrize("n", [6400, 10112])
+@pytest.mark.parametrize("form", ["chain", "chain3", "two_step", "one_kernel"])
+@pytest.mark.parametrize("split", ["2:0", "3:8"])
+def test_factor_tile_by_tile_with_split_update_ranges(form, split, monkeypatch):
+    """Round 5: the tasks of the late block columns hand the first part(s) of their update range to partial-sum tasks and add the sums
+    before they store / finish their tile (cholflow.hip, FLOW_PART; the default from 80 block columns on).  Forced here on 30 block
+    columns (2:0 = two pieces from the first column that is long enough, 16; 3:8 = three pieces, from column 24) under the forms that
+    run the tile kernel, tile by tile against LAPACK -- the diagonal and subdiagonal tiles of the chain forms are split like the others."""
+    import ctypes as C
+    monkeypatch.setenv("JAICOV_FLOW_MIN_BLOCKS", "1")
+    monkeypatch.setenv("JAICOV_FLOW_SPLIT", split)
+    if form != "chain":
+        monkeypatch.setenv("JAICOV_FACTOR_FORM", form)
+    lib = engine.load_library()
+    lib.jaicov_debug_potrf_factor.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+    n = 3840
+    rng = np.random.default_rng(n + len(form))
+    G = rng.normal(size=(n, n + 20))
+    S = np.ascontiguousarray(G @ G.T / n + np.eye(n))
+    out = np.zeros((n, n))
+    assert lib.jaicov_debug_potrf_factor(n, S.ctypes.data, out.ctypes.data) == 0
+    np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [6400, 10112, 10496])
 def test_factor_tile_by_tile_at_the_orders_between(n):
     """50 block columns: the chain form with its third workgroup (default below 80 block columns since round 4's last sweep); 79: the largest
-    order that runs so.  Held tile by tile against LAPACK like the small orders above."""
+    order that runs so; 82: two chain workgroups and, since round 5, split update ranges from block column 41 on (the default rule).
+    Held tile by tile against LAPACK like the small orders above."""
     import ctypes as C
     lib = engine.load_library()
     lib.jaicov_debug_potrf_factor.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
