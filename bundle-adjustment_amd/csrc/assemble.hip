@@ -753,7 +753,13 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
                 const int cqs[3] = {cur.cq[0], cur.cq[1], cur.cq[2]};
                 pp_products<FUSED>(cur, upc, sigma2, gq);
                 if (first) {                // my image's turn: o - ob images have been added
-                    while (__hip_atomic_load(det_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != o - ob) __builtin_amdgcn_s_sleep(0);
+                    // bounded: every image of [ob, oe) passes the turn today, but a wave that ever left early would otherwise
+                    // hang the GPU; on expiry (2^26 polls, seconds) the products are poisoned -- N gets NaNs, the solve reports NOT_FINITE
+                    int spin = 0;
+                    while (__hip_atomic_load(det_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != o - ob) {
+                        __builtin_amdgcn_s_sleep(0);
+                        if (++spin > (1 << 26)) { gq[0] = __builtin_nan(""); break; }
+                    }
                     asm volatile("" ::: "memory");
                 }
                 pp_apply(gq, cqs, apc, strip, cw, c0, cp0, cp1, cp2, wlo, whi);

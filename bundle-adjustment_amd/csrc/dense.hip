@@ -367,6 +367,8 @@ __device__ __forceinline__ void chain_ring_put(ChainRing &rg, int i, const doubl
 // and it sets `ready` for every entry whatever happened, so this loop ends whenever that one does -- and a predecessor that is
 // merely LATE is waited for as long as the polling wave waits, instead of being replaced by stale ring contents after a shorter
 // spin of this wave's own (a finite but wrong x_k; the tests rely on a lost link showing up as NaNs).
+// (No poll limit of its own: the only producer is this workgroup's polling wave, whose own wait for the predecessor IS limited
+// (BS_SPIN_MAX) and which then hands over the "not published" pattern -- every slot is filled after a bounded time, with a NaN at worst.)
 __device__ __forceinline__ int chain_ring_get(ChainRing &rg, int i) {
     const int slot = i & (CH_RD - 1);
     while (__hip_atomic_load(&rg.ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != i + 1) __builtin_amdgcn_s_sleep(0);

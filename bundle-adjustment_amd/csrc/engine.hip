@@ -335,7 +335,9 @@ __global__ void load_disp_batched_kernel(const DispDesc *__restrict__ desc, doub
     double v = (i == j) ? 1.0 : 0.0;
     if (i < dd.m && j < dd.m) {
         const int si = dd.perm ? 2 * dd.perm[i >> 1] + (i & 1) : i, sj = dd.perm ? 2 * dd.perm[j >> 1] + (j & 1) : j;
-        v = dd.src[(long)si * dd.m + sj];
+        // the LOWER triangle of the caller's array, mirrored (dpptrf / the per-matrix path of rounds 1-3 read nothing else: a caller that fills
+        // one triangle only, or a slightly asymmetric matrix, must not reach the Newton-Schulz step as a non-symmetric D)
+        v = si >= sj ? dd.src[(long)si * dd.m + sj] : dd.src[(long)sj * dd.m + si];
     }
     Lb[(long)blockIdx.z * msz + (long)i * ld + j] = v;
     if (Db) Db[(long)blockIdx.z * msz + (long)i * ld + j] = v;      // the refinement of the inverse reads the matrix once more
@@ -393,12 +395,12 @@ static int invert_dispersions(jaicov_engine *e, std::vector<DispItem> &items) {
     cstream = jaicov::stream_acquire(jaicov::STREAM_PLAIN);
     if (!cstream) FAIL(e, JAICOV_ERR_DEVICE, "no stream for the dispersion uploads");
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
-    for (int b = 0; b < 2; b++) {
-        HIPE(e, hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming));
-        HIPE(e, hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming));
-    }
     int status = JAICOV_OK;
     std::string msg;
+    for (int b = 0; b < 2 && status == JAICOV_OK; b++)      // (no early return from here on: the stream goes back to the pool and the events are destroyed below)
+        if (hipEventCreateWithFlags(&ev_up[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev_free[b], hipEventDisableTiming) != hipSuccess) {
+            status = JAICOV_ERR_DEVICE; msg = "inversion of the dispersion matrices: no events";
+        }
     for (size_t g0 = 0; g0 < items.size() && status == JAICOV_OK;) {
         const int mp = ((items[g0].m + 127) / 128) * 128;
         size_t g1 = g0;
@@ -453,7 +455,7 @@ static int invert_dispersions(jaicov_engine *e, std::vector<DispItem> &items) {
         else if (info != 0) { status = JAICOV_ERR_SINGULAR; msg = "dispersion matrix is not positive definite (MatrixNotSPDException, DOPG:85-86)"; }
         g0 = g1;
     }
-    for (int b = 0; b < 2; b++) { hipEventDestroy(ev_up[b]); hipEventDestroy(ev_free[b]); }
+    for (int b = 0; b < 2; b++) { if (ev_up[b]) hipEventDestroy(ev_up[b]); if (ev_free[b]) hipEventDestroy(ev_free[b]); }
     jaicov::stream_release(jaicov::STREAM_PLAIN, cstream);
     e->create_ms[1] = up_ms;
     e->create_ms[2] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count();
@@ -1620,6 +1622,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
             if ((size_t)I6p * ((size_t)2 * Up + I6p) > (size_t)slv.n * slv.ld)
                 FAIL(e, JAICOV_ERR_UNSUPPORTED, "FULL_EXPANDED: more exterior orientations than the workspace holds; use JAICOV_INVERT_FULL");
             double *Fm = slv.W, *T1 = Fm + (size_t)I6p * Up, *T2 = T1 + (size_t)I6p * Up;
+            const double *LinvAll = e->sb.Linv;
             if (e->all_images) {
                 HIPE(e, hipMemsetAsync(Fm, 0, (size_t)I6p * Up * sizeof(double), e->stream));
                 HIPE(e, launch_schur_expand_f(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->d_rowsA, e->sb.U, e->sb.Linv, e->sb.G, Fm, (long)Up));
@@ -1627,7 +1630,10 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
                 if (!e->exp_ready || e->expF_len != (size_t)I6p * Up + (size_t)36 * e->p.n_images)
                     FAIL(e, JAICOV_ERR_BAD_STATE, "FULL_EXPANDED on a sharded engine: all-reduce jaicov_neq_expansion_buffer() between accumulate and solve");
                 HIPE(e, hipMemcpyAsync(Fm, e->d_expF, (size_t)I6p * Up * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
-                HIPE(e, hipMemcpyAsync(e->sb.Linv, e->d_expF + (size_t)I6p * Up, (size_t)36 * e->p.n_images * sizeof(double), hipMemcpyDeviceToDevice, e->stream));
+                // the summed L_E^-1 records are READ from the buffer, never copied over sb.Linv: that array must keep zeros for the
+                // foreign images, or the next pass's expansion buffer would carry their stale records into the sum (ADVICE r4, high:
+                // a second sharded FULL_EXPANDED pass gave R times the EO cofactors)
+                LinvAll = e->d_expF + (size_t)I6p * Up;
             }
             HIPE(e, slv.symmetrize(slv.Q));
             GemmArgs g1{};
@@ -1639,7 +1645,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
             g2.M = I6p; g2.N = I6p; g2.K = Up; g2.alpha = -1.0; g2.beta = 0.0; g2.kmode = KMODE_FULL; g2.lower_only = 1;
             HIPE(e, gemm_f64(e->stream, LAY_KC, LAY_KC, g2));
             hipLaunchKernelGGL(expand_cofactor_kernel, dim3((e->U + 255) / 256, e->U), dim3(256), 0, e->stream, e->solver.Q, e->solver.ld,
-                               e->U, e->e0, slv.Q, ld, T1, (long)Up, T2, (long)I6p, e->sb.Linv);
+                               e->U, e->e0, slv.Q, ld, T1, (long)Up, T2, (long)I6p, LinvAll);
         }
         HIPE(e, hipEventRecord(e->ev[7], e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));

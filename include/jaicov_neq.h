@@ -333,18 +333,9 @@ int jaicov_neq_cancel(jaicov_engine *e);
  * [0] rows  [1] assembly  [2] finalize  [3] factorisation  [4] solve  [5] inverse  [6] omega  [7] total  */
 int jaicov_neq_last_timings(jaicov_engine *e, double *ms, int32_t n);
 
-/* Per-kernel profiling of the dominant kernel (the fp64 MFMA trailing update of the factorisation): when enabled,
- * every such launch is bracketed by HIP events on the engine stream.  stats: [0] launches, [1] summed device ms,
- * [2] summed algorithmic flops (rows*(rows+1)*K per lower-triangular update), since the last reset.  With n >= 6 and
- * assembly_mode = 1: [3] passes, [4] summed device ms of the two J'WJ GEMM launches per batch of images, [5] summed
- * algorithmic flops of SURVEY 8(d)'s dense-group row, sum_g 2 m^2 (k+1) + m (k+1)(k+2).
- * With n >= 10, health counters of the dataflow factorisation since jaicov_neq_create (not reset): [6] factorisations that were
- * abandoned on the device (a bounded wait ran out) and repeated, [7] flags that only the slow-path poll found, [8] of those the
- * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == 0 ([7]..[9] are informational:
- * the slow-path poll also finds flags that were simply set late); bench.py prints them and flags a line whose run repeated a factorisation.  With n >= 11: [10] the relative size of the last
- * refinement correction, max |correction| / max |dx| (= the error the unrefined step had).  With n >= 12: [11] the refinement steps
- * per solve the engine runs (option `refinement` after clamping).  With n >= 13: [12] the strip width (columns) of the point x point
- * gather, chosen at create from how an image's points spread over the columns.                                                   */
+/* Per-kernel profiling of the dominant kernel: the dataflow Cholesky's tile kernel (chol_tile_kernel, ONE persistent launch per
+ * factorisation from 12 block columns on; for smaller orders the trailing-update GEMM launches of the stream-scheduled form).  When
+ * enabled, every such launch is bracketed by a pair of HIP events on the stream it runs on; jaicov_neq_kernel_stats reads the sums.   */
 int jaicov_neq_set_profiling(jaicov_engine *e, int enable);
 /* What jaicov_neq_create spent (ms, wall clock of the host): [0] the whole call, [1] host time inside the uploads of the dense
  * dispersions (pageable host memory -> device), [2] dispersions -> weights altogether (upload + batched inversion, DOPG:82-86),
@@ -355,7 +346,27 @@ int jaicov_neq_create_timings(jaicov_engine *e, double *ms, int32_t n);
  * sigma0^2 times it), row-major m x m with m = 2 * (points of the block), rows and columns in the caller's observation order;
  * len must be m * m.                                                                                                            */
 int jaicov_neq_get_block_weight(jaicov_engine *e, int32_t block, double *out, size_t len);
+/* stats: [0] launches of the dominant kernel, [1] their summed device ms, [2] their summed algorithmic flops (order^3 / 3 per dataflow
+ * factorisation; rows (rows + 1) K per lower-triangular update of the stream-scheduled form), since the last reset (needs
+ * jaicov_neq_set_profiling).  With n >= 6 and assembly_mode = 1: [3] passes, [4] summed device ms of the two J'WJ GEMM launches per batch of
+ * images, [5] summed algorithmic flops of SURVEY 8(d)'s dense-group row, sum_g 2 m^2 (k+1) + m (k+1)(k+2).
+ * With n >= 10, health counters of the dataflow factorisation since jaicov_neq_create (not reset): [6] factorisations that were
+ * abandoned on the device (a bounded wait ran out) and repeated, [7] flags that only the slow-path poll found, [8] of those the
+ * ones the plain poll still missed, [9] the ones found after more than 1 ms of waiting.  A healthy run has [6] == 0 ([7]..[9] are informational:
+ * the slow-path poll also finds flags that were simply set late); bench.py prints them and flags a line whose run repeated a factorisation.
+ * With n >= 11: [10] the relative size of the last refinement correction, max |correction| / max |dx| (= the error the unrefined step had).
+ * With n >= 12: [11] the refinement steps per solve the engine runs (option `refinement` after clamping).  With n >= 13: [12] the strip width
+ * (columns) of the point x point gather, chosen at create from how an image's points spread over the columns.                          */
 int jaicov_neq_kernel_stats(jaicov_engine *e, double *stats, int32_t n, int reset);
+
+/* THE ENVIRONMENT IS NOT AN INTERFACE.  The library reads a handful of variables; none of them is a supported way to configure a run:
+ *   test hooks that select a SECOND numerical path so that the test-suite can hold it to the same parity as the default
+ *   (tests/test_gpu_parity.py names each): JAICOV_FACTOR_FORM (form of the factorisation: streams, two_step, one_kernel, chain2, chain3),
+ *   JAICOV_ASSEMBLY_FORM (t_vector, materialise), JAICOV_FLOW_MIN_BLOCKS (smallest order that takes the dataflow factorisation),
+ *   JAICOV_CHAIN8_MIN_NB (smallest order that takes the polling-wave substitution chains), JAICOV_FLOW_SPLIT ("m:from": split update
+ *   ranges of the dataflow factorisation), JAICOV_FLOW_TIMEOUT_MS (time limit of a wait: the tests of the repeat path set 0);
+ *   diagnostics: JAICOV_VERBOSE, JAICOV_FLOW_TRACE_ON, JAICOV_CHAIN_TRACE, JAICOV_TRACE_TAG, JAICOV_TRACE_WARM.
+ * Results are the same (to rounding) under every one of them; what a host may configure is jaicov_engine_options.                        */
 
 #ifdef __cplusplus
 }

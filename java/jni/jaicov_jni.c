@@ -14,6 +14,7 @@
  * Every pinned pointer is released with the pointer it was pinned with.
  */
 #include <jni.h>
+#include <stddef.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -62,8 +63,41 @@ static void unhold(JNIEnv *e, held_t *h) {
     h->ptr = NULL;
 }
 
-JNIEXPORT jlong JNICALL NAT(create)(JNIEnv *e, jclass k, jobject d, jint device, jint imageBegin, jint imageEnd, jboolean applyShared) {
+/* EngineOptions (Java) -> jaicov_engine_options, field for field; returns -1 with a JNI exception pending when a field is missing */
+static int read_options(JNIEnv *e, jobject opt, jaicov_engine_options *o) {
+    memset(o, 0, sizeof(*o));
+    o->struct_size = sizeof(*o);
+    o->image_begin = o->image_end = -1;
+    o->apply_shared = 1;
+    if (!opt) return 0;                                  /* null = all defaults, all images, device 0 */
+    jclass oc = (*e)->GetObjectClass(e, opt);
+    static const struct { const char *name; size_t off; } I[] = {
+        {"device", offsetof(jaicov_engine_options, device)},
+        {"imageBegin", offsetof(jaicov_engine_options, image_begin)},
+        {"imageEnd", offsetof(jaicov_engine_options, image_end)},
+        {"assemblyMode", offsetof(jaicov_engine_options, assembly_mode)},
+        {"blockSize", offsetof(jaicov_engine_options, block_size)},
+        {"reducedReferenceQuirk", offsetof(jaicov_engine_options, reduced_reference_quirk)},
+        {"deterministic", offsetof(jaicov_engine_options, deterministic)},
+        {"refinement", offsetof(jaicov_engine_options, refinement)},
+        {"ordinaryGroupElimination", offsetof(jaicov_engine_options, ordinary_group_elimination)},
+        {"dispersionRefinement", offsetof(jaicov_engine_options, dispersion_refinement)},
+        {"expansionExchange", offsetof(jaicov_engine_options, expansion_exchange)}};
+    for (size_t q = 0; q < sizeof(I) / sizeof(I[0]); q++) {
+        jfieldID f = (*e)->GetFieldID(e, oc, I[q].name, "I");
+        if (!f) return -1;
+        *(int32_t *)((char *)o + I[q].off) = (int32_t)(*e)->GetIntField(e, opt, f);
+    }
+    jfieldID fs = (*e)->GetFieldID(e, oc, "applyShared", "Z");
+    if (!fs) return -1;
+    o->apply_shared = (*e)->GetBooleanField(e, opt, fs) ? 1 : 0;
+    return 0;
+}
+
+JNIEXPORT jlong JNICALL NAT(create)(JNIEnv *e, jclass k, jobject d, jobject options) {
     (void)k;
+    jaicov_engine_options o;
+    if (read_options(e, options, &o)) return 0;
     jclass c = (*e)->GetObjectClass(e, d);
     jaicov_problem_desc p;
     memset(&p, 0, sizeof(p));
@@ -118,13 +152,6 @@ JNIEXPORT jlong JNICALL NAT(create)(JNIEnv *e, jclass k, jobject d, jint device,
         p.n_scale_bars = a[SB_A].len;
         p.n_direct_groups = a[DG_BEGIN].len > 0 ? a[DG_BEGIN].len - 1 : 0;
         p.n_direct_rows = a[DG_SLOT].len;
-        jaicov_engine_options o;
-        memset(&o, 0, sizeof(o));
-        o.struct_size = sizeof(o);
-        o.device = device;
-        o.image_begin = imageBegin;
-        o.image_end = imageEnd;
-        o.apply_shared = applyShared ? 1 : 0;
         rc = jaicov_neq_create(&p, &o, &eng);            /* copies everything it keeps */
         if (rc != JAICOV_OK) {
             strncpy(msg, eng ? jaicov_neq_last_error(eng) : "jaicov_neq_create failed", sizeof(msg) - 1);
@@ -184,6 +211,87 @@ JNIEXPORT jint JNICALL NAT(reduceBuffer)(JNIEnv *e, jclass k, jlong h, jlongArra
     jlong v[2] = {(jlong)(intptr_t)ptr, (jlong)cnt};
     if ((*e)->GetArrayLength(e, out) < 2) return JAICOV_ERR_BAD_ARGUMENT;
     (*e)->SetLongArrayRegion(e, out, 0, 2, v);
+    return rc;
+}
+/* device pointer + count (+ stream) triples of the three exchange buffers of a sharded run */
+static jint put_longs(JNIEnv *e, jlongArray out, int rc, const jlong *v, jsize n) {
+    if ((*e)->GetArrayLength(e, out) < n) return JAICOV_ERR_BAD_ARGUMENT;
+    (*e)->SetLongArrayRegion(e, out, 0, n, v);
+    return rc;
+}
+/* out = {device address, count, hipStream_t}: the collective is enqueued on that stream, no host wait (jaicov_neq_reduce_buffer_async) */
+JNIEXPORT jint JNICALL NAT(reduceBufferAsync)(JNIEnv *e, jclass k, jlong h, jlongArray out) {
+    (void)k;
+    void *ptr = NULL, *st = NULL;
+    size_t cnt = 0;
+    int rc = jaicov_neq_reduce_buffer_async(ENG(h), &ptr, &cnt, &st);
+    jlong v[3] = {(jlong)(intptr_t)ptr, (jlong)cnt, (jlong)(intptr_t)st};
+    return put_longs(e, out, rc, v, 3);
+}
+/* the sharded FINAL pass of MatrixInversion.FULL (BA:268-271 per rank): [F | L_E^-1] of this rank's images, summed over the ranks */
+JNIEXPORT jint JNICALL NAT(expansionBuffer)(JNIEnv *e, jclass k, jlong h, jlongArray out) {
+    (void)k;
+    void *ptr = NULL;
+    size_t cnt = 0;
+    int rc = jaicov_neq_expansion_buffer(ENG(h), &ptr, &cnt);
+    jlong v[2] = {(jlong)(intptr_t)ptr, (jlong)cnt};
+    return put_longs(e, out, rc, v, 2);
+}
+/* the EO steps this rank back-substituted (6 per image), summed over the ranks into dx's EO entries */
+JNIEXPORT jint JNICALL NAT(eoStepBuffer)(JNIEnv *e, jclass k, jlong h, jlongArray out) {
+    (void)k;
+    void *ptr = NULL;
+    size_t cnt = 0;
+    int rc = jaicov_neq_eo_step_buffer(ENG(h), &ptr, &cnt);
+    jlong v[2] = {(jlong)(intptr_t)ptr, (jlong)cnt};
+    return put_longs(e, out, rc, v, 2);
+}
+JNIEXPORT jint JNICALL NAT(abiVersion0)(JNIEnv *e, jclass k) { (void)e; (void)k; return jaicov_neq_abi_version(); }
+/* small double[] out-parameters: filled through a stack copy (no array pinned across the call) */
+static jint put_doubles(JNIEnv *e, jdoubleArray out, int rc, const double *v, jsize have) {
+    jsize n = (*e)->GetArrayLength(e, out);
+    (*e)->SetDoubleArrayRegion(e, out, 0, n < have ? n : have, v);
+    return rc;
+}
+JNIEXPORT jint JNICALL NAT(lastTimings)(JNIEnv *e, jclass k, jlong h, jdoubleArray ms) {
+    (void)k;
+    double v[8] = {0};
+    return put_doubles(e, ms, jaicov_neq_last_timings(ENG(h), v, 8), v, 8);
+}
+JNIEXPORT jint JNICALL NAT(createTimings)(JNIEnv *e, jclass k, jlong h, jdoubleArray ms) {
+    (void)k;
+    double v[8] = {0};
+    return put_doubles(e, ms, jaicov_neq_create_timings(ENG(h), v, 8), v, 8);
+}
+JNIEXPORT jint JNICALL NAT(setProfiling)(JNIEnv *e, jclass k, jlong h, jboolean on) { (void)e; (void)k; return jaicov_neq_set_profiling(ENG(h), on ? 1 : 0); }
+JNIEXPORT jint JNICALL NAT(kernelStats)(JNIEnv *e, jclass k, jlong h, jdoubleArray stats, jboolean reset) {
+    (void)k;
+    double v[16] = {0};
+    return put_doubles(e, stats, jaicov_neq_kernel_stats(ENG(h), v, 16, reset ? 1 : 0), v, 16);
+}
+/* PDF:285-445 for the image points [begin, begin + count): w has 2 count entries, A 2 count (12 + JAICOV_MAX_DIST_PER_CAMERA) */
+JNIEXPORT jint JNICALL NAT(getRows)(JNIEnv *e, jclass k, jlong h, jint begin, jint count, jdoubleArray w, jdoubleArray A) {
+    (void)k;
+    if (count < 0 || (*e)->GetArrayLength(e, w) < 2 * count ||
+        (*e)->GetArrayLength(e, A) < 2 * count * (12 + JAICOV_MAX_DIST_PER_CAMERA)) return JAICOV_ERR_BAD_ARGUMENT;
+    double *pw = (double *)(*e)->GetDoubleArrayElements(e, w, NULL);          /* small: a copy, so that only ONE array is pinned */
+    if (!pw) return JAICOV_ERR_OUT_OF_MEMORY;
+    double *pA = (double *)(*e)->GetPrimitiveArrayCritical(e, A, NULL);
+    int rc = JAICOV_ERR_OUT_OF_MEMORY;
+    if (pA) {
+        rc = jaicov_neq_get_rows(ENG(h), (int32_t)begin, (int32_t)count, pw, pA);
+        (*e)->ReleasePrimitiveArrayCritical(e, A, pA, 0);
+    }
+    (*e)->ReleaseDoubleArrayElements(e, w, pw, 0);
+    return rc;
+}
+JNIEXPORT jint JNICALL NAT(getBlockWeight)(JNIEnv *e, jclass k, jlong h, jint block, jdoubleArray out) {
+    (void)k;
+    jsize n = (*e)->GetArrayLength(e, out);
+    double *p = (double *)(*e)->GetPrimitiveArrayCritical(e, out, NULL);
+    if (!p) return JAICOV_ERR_OUT_OF_MEMORY;
+    int rc = jaicov_neq_get_block_weight(ENG(h), (int32_t)block, p, (size_t)n);
+    (*e)->ReleasePrimitiveArrayCritical(e, out, p, 0);
     return rc;
 }
 JNIEXPORT jint JNICALL NAT(prepareInverse)(JNIEnv *e, jclass k, jlong h, jint invert) { (void)e; (void)k; return jaicov_neq_prepare_inverse(ENG(h), (int)invert); }

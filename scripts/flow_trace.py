@@ -150,3 +150,11 @@ if want_trace and nt.value:
             z = cu[c, 0]
             a = tix.get((c + 1, c - 1)); b = tix[(c + 1, c)]; d = tix[(c + 1, c + 1)]
             print(f"{c}: 0 {cu[c, 1] - z:.0f} | {us[a, 2] - z:.0f} {us[a, 3] - z:.0f} | {us[b, 0] - z:.0f} {us[b, 1] - z:.0f} {us[b, 2] - z:.0f} {us[b, 3] - z:.0f} runs {runs[b]} waited {wait[b]:.0f} | {us[d, 3] - z:.0f} | {cu[c, 2] - z:.0f} {cu[c, 3] - z:.0f} {cu[c, 4] - z:.0f}")
+    if os.environ.get("FLOW_TRACE_ROW") and ct[:, 0].any():
+        # one block row near the end: link by link, when is L[r][k] final, when has tile (r, k+1) its last update, when is potrf(k+1) done
+        r, lo, hi = [int(v) for v in os.environ["FLOW_TRACE_ROW"].split(":")]
+        print(f"row {r}: k | potrf(k) done | tile (r,k): updates done, final (finish = wait for the inverse + product + store) | step of (r,k+1) after L[r][k] | after potrf(k) done")
+        for k in range(lo, hi):
+            a = tix[(r, k)]; b = tix.get((r, k + 1))
+            fk = cu[k, 1]
+            print(f"  {k}: {fk:.0f} | {us[a, 2]:.0f} {us[a, 3]:.0f} (finish {us[a, 3] - us[a, 2]:.0f}) | {(us[b, 2] - us[a, 3]) if b is not None else 0:.0f} | updates done {us[a, 2] - fk:.0f}, final {us[a, 3] - fk:.0f} after potrf(k)")

@@ -27,6 +27,7 @@ struct JNINativeInterface_ {
     jfieldID (*GetFieldID)(JNIEnv *, jclass, const char *, const char *);
     jobject (*GetObjectField)(JNIEnv *, jobject, jfieldID);
     jint (*GetIntField)(JNIEnv *, jobject, jfieldID);
+    jboolean (*GetBooleanField)(JNIEnv *, jobject, jfieldID);
     jstring (*NewStringUTF)(JNIEnv *, const char *);
     jsize (*GetArrayLength)(JNIEnv *, jarray);
     jint *(*GetIntArrayElements)(JNIEnv *, jintArray, jboolean *);

@@ -43,6 +43,11 @@ def _worker(rank, world, port, out_dir):
     dxf = distributed.sharded_step(eng, dist, dev, fp.sigma2apriori, 0.0, invert=engine.INVERT_FULL_EXPANDED)
     assert eng.cofactor_order() == fp.n_unknowns and eng.reduced_order() == fp.n_unknowns - 6 * fp.n_images
     res += [dxf, eng.get_cofactor()]
+    # ... and a SECOND expanded pass on the same engines after the parameters have moved (the first pass used to leave the
+    # other rank's L_E^-1 records in this engine's array, and the next expansion buffer carried them into the sum: EO cofactors R times too large)
+    eng.update(dxf)
+    dxg = distributed.sharded_step(eng, dist, dev, fp.sigma2apriori, 0.0, invert=engine.INVERT_FULL_EXPANDED)
+    res += [dxg, eng.get_cofactor(), eng.get_parameters()]
     np.save(os.path.join(out_dir, f"r{rank}.npy"), np.concatenate(res))
     eng.close()
     dist.barrier()
@@ -67,6 +72,13 @@ def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle_mod):
     dxo, Qo, _, _ = o.step(fp.values, fp.sigma2apriori, 0.0, True)          # dspsv + dsptri at full order (MX:338-366)
     base = 2 * (U + 1)
     np.testing.assert_allclose(r0[base:base + U], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
-    Q = r0[base + U:]
-    assert Q.size == Qo.size
+    nq = Qo.size
+    Q = r0[base + U:base + U + nq]
     np.testing.assert_allclose(Q, Qo, rtol=0, atol=1e-9 * np.abs(Qo).max())
+    # the second expanded pass, at the parameters the engines moved to
+    base += U + nq
+    vals = r0[base + U + nq:]
+    assert vals.size == fp.values.size
+    dxo2, Qo2, _, _ = o.step(vals, fp.sigma2apriori, 0.0, True)
+    np.testing.assert_allclose(r0[base:base + U], dxo2, rtol=0, atol=1e-9 * max(np.abs(dxo2).max(), np.abs(dxo).max()))
+    np.testing.assert_allclose(r0[base + U:base + U + nq], Qo2, rtol=0, atol=1e-9 * np.abs(Qo2).max())
