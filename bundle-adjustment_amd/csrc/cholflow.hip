@@ -1122,7 +1122,11 @@ hipError_t DenseSolver::flow_init() {
         flow_flags = nullptr;
         (void)hipGetLastError();
     }
-    if (!flow_flags) HIPCHK(hipMalloc(&flow_flags, flow_words * sizeof(int)));
+    if (!flow_flags) {
+        // (seen to matter: in ordinary memory a flag store can stay invisible to the other XCDs' polls for as long as the kernel runs)
+        fprintf(stderr, "jaicov: no fine-grained device memory for the flags of the dataflow factorisation (%zu words): ordinary memory, rare stalls possible\n", flow_words);
+        HIPCHK(hipMalloc(&flow_flags, flow_words * sizeof(int)));
+    }
     HIPCHK(hipMemset(flow_flags, 0, flow_words * sizeof(int)));
     int cus = 256;
     hipDeviceProp_t prop;
@@ -1321,6 +1325,27 @@ void DenseSolver::flow_report_stall() {
             if (flow_task_host[t].x == i && flow_task_host[t].y == j) return t;
         return -1;
     };
+    // What every workgroup was doing at the MOMENT the first wait ran out (flow_give_up's copy of the state words): the ones that were not
+    // waiting then -- inside the products, storing, adding partial sums -- are the ones the others were waiting for.
+    {
+        int by_stage[16] = {0};
+        std::vector<std::pair<int, int>> busy;
+        for (int b = 0; b < std::min(flow_grid, 1024); b++) {
+            const int w = wg[1024 + b];
+            if (w == 0) continue;
+            by_stage[w & 15]++;
+            if ((w & 15) == 4 || (w & 15) == 5 || (w & 15) == 6 || (w & 15) == 1) busy.push_back({w >> 12, b});
+        }
+        std::sort(busy.begin(), busy.end());
+        fprintf(stderr, "jaicov:   when the first wait ran out: workgroups by stage [1 drawn %d, 2 waits for a visit / the inverse %d, 3 polls operands %d, 4 products %d, 5 / 6 stores %d / %d, 7 between tasks %d, 9 waits for partial sums %d]\n",
+                by_stage[1], by_stage[2], by_stage[3], by_stage[4], by_stage[5], by_stage[6], by_stage[7], by_stage[9]);
+        for (size_t q = 0; q < busy.size() && q < 8; q++) {
+            const int w = wg[1024 + busy[q].second], t = w >> 12;
+            const int4 tk = (t >= 0 && t < (int)flow_task_host.size()) ? flow_task_host[t] : make_int4(-1, -1, 0, 0);
+            fprintf(stderr, "jaicov:     not waiting then: workgroup %d, ticket %d = tile (%d, %d)%s, stage %d at block column %d; now: stage %d at block column %d\n", busy[q].second, t, tk.x, tk.y,
+                    (tk.w & FLOW_PART) ? " partial sum" : "", w & 15, (w >> 4) & 255, wg[busy[q].second] & 15, (wg[busy[q].second] >> 4) & 255);
+        }
+    }
     for (size_t q = 0; q < open.size() && q < 6; q++) {
         const int w = wg[open[q].second], t = w >> 12;
         const int4 tk = flow_task_host.empty() ? make_int4(-1, -1, 0, 0) : flow_task_host[t];

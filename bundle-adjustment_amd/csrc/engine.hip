@@ -610,6 +610,15 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             }
             // (the dense form of the block-diagonal weights -- the alternative assembly forms only -- needs m^2 doubles per image)
             ok = ok && any && (assembly_form() == ASSEMBLY_DEFAULT || assembly_form() == ASSEMBLY_NO_FORK || syn_bytes <= ((int64_t)16 << 30));
+            // Size rule (round 5; option 0 = default): serving ordinary images as blocks costs six block-kernel launches where the ordinary assembly
+            // is one (+0.10 ms per pass at BASELINE config 2), and pays through the factorisation's block columns: eliminate when the 6 I exterior-
+            // orientation columns are at least two 128-blocks of it (config 2: order 726 -> 606, six block columns -> five: not worth it, 0.79 vs
+            // 0.86 ms per pass; config 3: 29 -> 24, the bundled example 10 -> 4: yes).  A property of the WHOLE problem, so every rank of a
+            // sharded run decides alike.  > 0 forces the elimination at any size (tests), < 0 switches it off.
+            // (A problem that ALSO has jointly dispersed images runs the block kernels anyway, and only with every image served as a block
+            // can any exterior orientation be eliminated: no size rule there.)
+            if (ok && e->opts.ordinary_group_elimination == 0 && D->n_image_blocks == 0)
+                ok = (U + 127) / 128 - (U - 6 * D->n_images + 127) / 128 >= 2;
         }
         if (ok) {
             syn_begin.push_back(0);

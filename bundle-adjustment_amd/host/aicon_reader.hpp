@@ -158,10 +158,12 @@ inline void read_scale(AiconProject &pr, const std::string &path) {
 }
 
 // ExampleFlatFiles.java:76-103 order: obc, scale, ior, eor, phc
-inline std::unique_ptr<AiconProject> read_aicon_flat(const std::string &basepath) {
+// `extra`: distortion model types the camera carries beside the three of the .ior file (IORFileReader's varargs constructor,
+// ExampleDistortionModel.java:77: ZERNIKE_GRADIENT, ZERNIKE_X, ZERNIKE_Y)
+inline std::unique_ptr<AiconProject> read_aicon_flat(const std::string &basepath, std::vector<DistortionModel::Type> extra = {}) {
     std::unique_ptr<AiconProject> pr(new AiconProject());
     read_obc(*pr, basepath + ".obc");
-    read_ior(*pr, basepath + ".ior");
+    read_ior(*pr, basepath + ".ior", extra);
     read_scale(*pr, basepath + ".scale");
     read_eor(*pr, basepath + ".eor");
     read_phc(*pr, basepath + ".phc");

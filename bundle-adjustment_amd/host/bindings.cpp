@@ -218,7 +218,8 @@ PYBIND11_MODULE(_jaicov_host, m) {
             for (auto &q : p.scaleBars) v.push_back(q.get());
             return v;
         }, py::return_value_policy::reference_internal);
-    m.def("read_aicon_flat", [](const std::string &base) { return read_aicon_flat(base).release(); }, py::return_value_policy::take_ownership,
+    m.def("read_aicon_flat", [](const std::string &base, std::vector<DistortionModel::Type> extra) { return read_aicon_flat(base, extra).release(); },
+          py::arg("base"), py::arg("extra") = std::vector<DistortionModel::Type>{}, py::return_value_policy::take_ownership,
           "AICON flat files <base>.{obc,ior,scale,eor,phc} -> object graph (ExampleFlatFiles.java:76-103)");
     m.def("read_aicon_report", [](const std::string &path) { return read_aicon_report(path).release(); }, py::return_value_policy::take_ownership,
           "AICON 3D Studio adjustment report (.htm) -> object graph (AICONReportFileReader.java:117-390)");

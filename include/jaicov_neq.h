@@ -175,8 +175,10 @@ typedef struct jaicov_engine_options {
                                       not directly observed) the exterior orientations of images whose points are ORDINARY ImageCoordinate
                                       groups (diagonal / 2 x 2 weights) are pre-eliminated on the device like those of jointly dispersed
                                       images -- reduceNormalEquationSystem, BA:1197-1342, serves every image --: such an image is held as an
-                                      image block whose block-diagonal inv(D) is kept as 2 x 2 blocks (24 bytes per observation).  < 0: off, ordinary
-                                      groups are assembled one by one into the full-order system (the path of rounds 1-3).               */
+                                      image block whose block-diagonal inv(D) is kept as 2 x 2 blocks (24 bytes per observation) -- provided the
+                                      6 I exterior-orientation columns are at least two 128-column blocks of the factorisation (below that the
+                                      block kernels' launches cost more than the smaller system saves: BASELINE config 2).  > 0: eliminate at any
+                                      size.  < 0: off, ordinary groups are assembled one by one into the full-order system (rounds 1-3).    */
     int32_t  dispersion_refinement; /* 0 = default: every inverse dispersion (DOPG:82-86) gets one Newton-Schulz step X <- X + X (I - D X) at
                                       create, with the residual formed by error-free splitting on the fp64 matrix cores (batchinv.hip): the
                                       forward error of inv(D) falls from cond(D) * eps (3e-11 at config 4, the reference's dpptrf + dpptri the

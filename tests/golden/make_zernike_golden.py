@@ -24,6 +24,12 @@ SETS = {
     "zernike_y": [("ZY", 5), ("ZY", 10), ("ZY", 12)],
     "zernike_gradient": [("ZZ", 3), ("ZZ", 5), ("ZZ", 11), ("ZZ", 24)],
     "zernike_mixed": [("AI", 1), ("ZX", 12), ("ZY", 14), ("ZZ", 4)],
+    # round 5: the radial orders of the reference's third example (ExampleDistortionModel.java:95-99: single indices 4, 12, 24, 40, 60 =
+    # Z_2^0 .. Z_10^0: six radial terms, binomials up to C(10, 5), rho^10) -- for the gradient model as the example uses them, and the two
+    # highest for the X and Y models.  (Appended: the sets above keep their random draws, the file's earlier sets are unchanged.)
+    "zernike_high_x": [("ZX", 40), ("ZX", 60)],
+    "zernike_high_y": [("ZY", 40), ("ZY", 60)],
+    "zernike_example_gradient": [("ZZ", 4), ("ZZ", 12), ("ZZ", 24), ("ZZ", 40), ("ZZ", 60)],
 }
 
 

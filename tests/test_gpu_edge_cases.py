@@ -25,13 +25,13 @@ def renumber(fp, *, point_fixed=None, io_fixed=None, dist_fixed=None, eo_fixed=N
                                n_observations=0, **changes).validate()
 
 
-def check_against_oracle(oracle_mod, fp, invert=True):
+def check_against_oracle(oracle_mod, fp, invert=True, **engine_options):
     o = oracle_mod.Oracle(fp)
     s2 = fp.sigma2apriori
     U, d = fp.n_unknowns, fp.rank_defect
     No, no, _ = o.build(fp.values, s2, 0.0)
     dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, invert)
-    eng = engine.Engine(fp)
+    eng = engine.Engine(fp, **engine_options)
     eng.set_parameters(fp.values)
     eng.prepare_inverse(engine.INVERT_FULL)
     eng.build(s2, 0.0)

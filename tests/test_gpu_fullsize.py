@@ -171,3 +171,99 @@ def test_cfg4_abandoned_factorisation_is_reported_and_the_engine_stays_usable(cf
     eng.close()
     # two assemblies of the same system differ in the last bits (atomics); through cond 1e9 that is 1e-9..1e-8 of a single step
     np.testing.assert_allclose(again, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+
+
+def test_cfg4_two_shards_on_one_gpu(cfg4):
+    """VERDICT r4 (missing 6): the sharded path at the HEADLINE size inside the suite.  Two engines over 250 + 250 images of config 4 on
+    one GPU (what two ranks hold), their reduce buffers (0.90 GB each: packed reduced system + n + the damping's diagonal corrections)
+    summed on the device as RCCL's all-reduce would, one LM step; then the FULL final pass expanded from the reduced inverse, the
+    371 MB expansion buffers [F | L_E^-1] summed the same way -- twice, the second time after the parameters have moved.
+    Held to the oracle fixtures of tests/golden/cfg4 at the tolerances of tests/test_gpu_cfg4_golden.py, and to the unsharded engine."""
+    import json
+    import os
+    import torch
+    from bundle_adjustment_amd import distributed
+    from bundle_adjustment_amd.distributed import DeviceArray
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4")
+    z = dict(np.load(os.path.join(G, "cfg4_oracle.npz")))
+    fp = cfg4
+    s2, U = fp.sigma2apriori, fp.n_unknowns
+    dev = torch.device("cuda", 0)
+    parts = distributed.partition_images(fp, 2)
+    assert parts[0][0] == 0 and parts[0][1] == parts[1][0] and parts[1][1] == fp.n_images
+    engs = [engine.Engine(fp, image_range=parts[r], apply_shared=(r == 0), expansion_exchange=True) for r in range(2)]
+    for e in engs:
+        e.set_parameters(fp.values)
+
+    def summed(bufs):
+        ts = [torch.as_tensor(DeviceArray(p, c), device=dev) for p, c in bufs]
+        assert ts[0].numel() == ts[1].numel()
+        tot = ts[0] + ts[1]
+        for t in ts:
+            t.copy_(tot)
+        torch.cuda.synchronize(dev)
+        return ts[0].numel()
+
+    def sharded_pass(invert):
+        for e in engs:
+            e.prepare_inverse(invert)
+            e.accumulate(s2, 0.0)
+        n_red = summed([e.reduce_buffer() for e in engs])
+        n_exp = summed([e.expansion_buffer() for e in engs]) if invert == engine.INVERT_FULL_EXPANDED else 0
+        dxs = []
+        for e in engs:
+            e.finalize(s2, 0.0)
+            dxs.append(e.solve(invert))
+        e0 = engs[0].reduced_order()
+        np.testing.assert_array_equal(dxs[0][:e0], dxs[1][:e0])            # the replicated solve: the same bits on both shards
+        dx = dxs[0].copy()
+        dx[e0:] = dxs[0][e0:] + dxs[1][e0:]                                 # every shard back-substitutes its own images' EO
+        return dx, n_red, n_exp
+
+    dx, n_red, _ = sharded_pass(engine.INVERT_NONE)
+    e0 = engs[0].reduced_order()
+    assert e0 == U - 6 * fp.n_images and n_red >= e0 * (e0 + 1) // 2 + e0     # 1.13e8 doubles = 0.90 GB
+    assert np.abs(dx - z["dx1"]).max() < 1e-7 * np.abs(z["dx1"]).max()         # as test_pass1_assembly_and_step (achieved 2e-8)
+    one = engine.Engine(fp)
+    one.set_parameters(fp.values)
+    one.build(s2, 0.0)
+    dx_one = one.solve(False)
+    assert np.abs(dx - dx_one).max() < 1e-9 * np.abs(dx_one).max()             # two partial sums instead of one: rounding only
+    # second pass at the FIXTURE's linearisation point (the oracle's own first step), so that its dx2 and diag Qxx apply
+    cols = fp.slot_columns()
+    v2 = fp.values.copy()
+    v2[cols >= 0] += z["dx1"][cols[cols >= 0]]
+    for e in engs + [one]:
+        e.set_parameters(v2)
+    # the FULL final pass, expanded on shards
+    dx2, _, n_exp = sharded_pass(engine.INVERT_FULL_EXPANDED)
+    I6p = (6 * fp.n_images + 127) // 128 * 128
+    assert n_exp == I6p * ((e0 + 127) // 128 * 128) + 36 * fp.n_images        # 371 MB
+    assert engs[0].cofactor_order() == U
+    one.prepare_inverse(engine.INVERT_FULL_EXPANDED)
+    one.build(s2, 0.0)
+    dx2_one = one.solve(engine.INVERT_FULL_EXPANDED)
+    assert np.abs(dx2 - dx2_one).max() < 1e-8 * max(np.abs(dx2_one).max(), 1e-6)
+    idx = np.arange(0, U, 37, dtype=np.int32)                                  # 487 unknowns across points, interior orientation and every image's EO
+    Qs = [e.get_cofactor_sub(idx) for e in engs]
+    Q1 = one.get_cofactor_sub(idx)
+    np.testing.assert_array_equal(Qs[0], Qs[1])
+    sc = np.sqrt(np.abs(np.diag(Q1)))
+    assert np.abs((Qs[0] - Q1) / np.outer(sc, sc)).max() < 1e-8                # same algorithm, partial sums in another order
+    assert np.abs(dx2 - z["dx2"]).max() < 1e-7 * np.abs(z["dx2"]).max()       # the fixture's second pass (dspsv + dsptri at the updated values)
+    diag = np.concatenate([np.diag(engs[0].get_cofactor_sub(np.arange(a, min(a + 2048, U), dtype=np.int32)))
+                           for a in range(0, U, 2048)])
+    assert np.abs(diag - z["diagQ"]).max() / np.abs(z["diagQ"]).max() < 3e-7   # QTOL of test_gpu_cfg4_golden.py (the oracle's own distance from the truth)
+    # a second expanded pass after an update: the other shard's L_E^-1 records must not linger in this shard's arrays
+    for e in engs:
+        e.update(dx2)
+    one.update(dx2)
+    dx3, _, _ = sharded_pass(engine.INVERT_FULL_EXPANDED)
+    one.prepare_inverse(engine.INVERT_FULL_EXPANDED)
+    one.build(s2, 0.0)
+    one.solve(engine.INVERT_FULL_EXPANDED)
+    Q3, Q3_one = engs[1].get_cofactor_sub(idx), one.get_cofactor_sub(idx)
+    sc = np.sqrt(np.abs(np.diag(Q3_one)))
+    assert np.abs((Q3 - Q3_one) / np.outer(sc, sc)).max() < 1e-8
+    for e in engs + [one]:
+        e.close()

@@ -14,6 +14,10 @@ from bundle_adjustment_amd.problem import packed_to_full
 
 pytestmark = pytest.mark.gpu
 
+# Round 5: by default the engine eliminates ordinary images only when that saves two block columns of the factorisation (not on the small
+# scenes used here: config 2 runs 0.79 ms per pass without against 0.86 with); ordinary_group_elimination = 1 forces the path at any size.
+FORCE = 1
+
 
 SCENES = {
     "tiny": lambda: scene.config("tiny"),                # 2 x 2 weights, control points
@@ -30,7 +34,7 @@ def test_ordinary_images_are_pre_eliminated(oracle_mod, name, lam):
     assert fp.n_image_blocks == 0
     o = oracle_mod.Oracle(fp)
     dxo, _, No, no = o.step(fp.values, s2, lam, False)
-    eng = engine.Engine(fp)
+    eng = engine.Engine(fp, ordinary_group_elimination=FORCE)
     eng.set_parameters(fp.values)
     eng.build(s2, lam)
     assert eng.reduced_order() == U - 6 * fp.n_images                     # the EO columns are gone from the system
@@ -50,7 +54,7 @@ def test_ordinary_images_are_pre_eliminated(oracle_mod, name, lam):
     np.testing.assert_allclose(n, nref, rtol=0, atol=1e-11 * np.abs(nref).max())
     eng.close()
     # arrival-order sums (deterministic off): the other instances of the gather with compact block-diagonal weights, both systems
-    arr = engine.Engine(fp, deterministic=False)
+    arr = engine.Engine(fp, deterministic=False, ordinary_group_elimination=FORCE)
     arr.set_parameters(fp.values)
     arr.build(s2, lam)
     assert arr.reduced_order() == U - 6 * fp.n_images
@@ -78,7 +82,7 @@ def test_reduced_inverse_of_ordinary_images_is_the_block_of_the_full_cofactor(or
     o = oracle_mod.Oracle(fp)
     dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, True)
     Qo = packed_to_full(Qo, U)
-    eng = engine.Engine(fp)
+    eng = engine.Engine(fp, ordinary_group_elimination=FORCE)
     eng.set_parameters(fp.values)
     for inv in (engine.INVERT_REDUCED, engine.INVERT_FULL_EXPANDED):
         eng.prepare_inverse(inv)
@@ -96,14 +100,14 @@ def test_estimate_on_ordinary_images_matches_oracle(oracle_mod):
     """The whole loop (jaicov_neq_estimate, MatrixInversion.REDUCED) on BASELINE config 2 with the elimination on and off."""
     fp = scene.config("cfg2")
     vo, Qo, ro = oracle_mod.Oracle(fp).estimate()
-    for flag in (0, -1):
+    for flag in (FORCE, -1):
         eng = engine.Engine(fp, ordinary_group_elimination=flag)
         v, r = eng.estimate(invert=engine.INVERT_REDUCED)
         assert r.state == 1 and r.iterations == ro.iterations
         assert np.abs(v - vo).max() <= 1e-9 * 2000.0
         assert abs(r.omega - ro.omega) <= 1e-9 * ro.omega
         k, kr = eng.cofactor_order(), fp.n_unknowns - 6 * fp.n_images
-        assert k == (kr if flag == 0 else fp.n_unknowns)                 # without the elimination REDUCED is served by the full inverse (jaicov_neq.h)
+        assert k == (kr if flag == FORCE else fp.n_unknowns)                 # without the elimination REDUCED is served by the full inverse (jaicov_neq.h)
         assert eng.reduced_order() == k
         Q = packed_to_full(eng.get_cofactor(), k)[:kr, :kr]
         Qr = packed_to_full(Qo, fp.n_unknowns)[:kr, :kr]
@@ -128,7 +132,7 @@ def test_problems_that_do_not_qualify_keep_the_full_order_path(oracle_mod):
     o = oracle_mod.Oracle(fp2)
     s2 = fp2.sigma2apriori
     dxo, _, _, _ = o.step(fp2.values, s2, 0.0, False)
-    eng = engine.Engine(fp2)
+    eng = engine.Engine(fp2, ordinary_group_elimination=FORCE)
     eng.set_parameters(fp2.values)
     eng.build(s2, 0.0)
     assert eng.reduced_order() == fp2.n_unknowns
@@ -144,7 +148,7 @@ def test_batched_dispersion_inverse_matches_the_references_dpptri(oracle_mod, m_
     fp = scene.make_scene(6, int(m_points / 0.55) + 12, m_points, dist=scene.DIST_RADIAL, weights="block", n_control=4, control_dense=True)
     o = oracle_mod.Oracle(fp)
     s2 = fp.sigma2apriori
-    eng = engine.Engine(fp)
+    eng = engine.Engine(fp, ordinary_group_elimination=FORCE)
     for b in range(fp.n_image_blocks):
         W = eng.get_block_weight(b) * s2
         ref = o.block_weight(s2, b)
@@ -162,7 +166,7 @@ def test_not_positive_definite_dispersion_is_reported():
     D = fp.blk_disp[off:off + m * m].reshape(m, m)
     D[3, 3] = -D[3, 3]
     with pytest.raises(engine.EngineError) as ei:
-        engine.Engine(fp)
+        engine.Engine(fp, ordinary_group_elimination=FORCE)
     assert ei.value.code == 1                                             # JAICOV_ERR_SINGULAR: MatrixNotSPDException (DOPG:85-86)
 
 
@@ -172,11 +176,11 @@ def test_ordinary_images_sharded(oracle_mod):
     fp = scene.config("tiny")
     s2 = fp.sigma2apriori
     dxo, _, _, _ = oracle_mod.Oracle(fp).step(fp.values, s2, 0.0, False)
-    full = engine.Engine(fp); full.set_parameters(fp.values); full.build(s2); N, n = full.get_normal()
+    full = engine.Engine(fp, ordinary_group_elimination=FORCE); full.set_parameters(fp.values); full.build(s2); N, n = full.get_normal()
     e0 = full.reduced_order()
     assert e0 == fp.n_unknowns - 6 * fp.n_images
-    a = engine.Engine(fp, image_range=(0, 2), apply_shared=True)
-    b = engine.Engine(fp, image_range=(2, fp.n_images), apply_shared=False)
+    a = engine.Engine(fp, image_range=(0, 2), apply_shared=True, ordinary_group_elimination=FORCE)
+    b = engine.Engine(fp, image_range=(2, fp.n_images), apply_shared=False, ordinary_group_elimination=FORCE)
     for e_ in (a, b):
         e_.set_parameters(fp.values); e_.accumulate(s2)
         assert e_.reduced_order() == e0
@@ -197,7 +201,7 @@ def test_simulation_on_ordinary_images_leaves_parameters_and_gives_the_oracles_c
     U = fp.n_unknowns
     Qo = packed_to_full(Qo, U)
     for inv in (engine.INVERT_REDUCED, engine.INVERT_FULL):
-        eng = engine.Engine(fp)
+        eng = engine.Engine(fp, ordinary_group_elimination=FORCE)
         v, r = eng.estimate(invert=inv, simulation=True)
         assert r.state == 1
         np.testing.assert_array_equal(v, fp.values)
@@ -229,7 +233,7 @@ def test_two_cameras_with_ordinary_images(oracle_mod):
                       dist_order=np.concatenate([base.dist_order, base.dist_order[keep]]).astype(np.int32),
                       values=values, truth=None)
     assert two.n_image_blocks == 0
-    reduced = ec.check_against_oracle(oracle_mod, two)
+    reduced = ec.check_against_oracle(oracle_mod, two, ordinary_group_elimination=FORCE)
     assert reduced
 
 
@@ -240,7 +244,7 @@ def test_a_large_ordinary_problem_is_eliminated_with_compact_weights():
     fp = scene.make_scene(140, 4000, 2000, dist=scene.DIST_RADIAL, weights="2x2", n_control=6)
     U, s2 = fp.n_unknowns, fp.sigma2apriori
     assert fp.n_image_blocks == 0 and 140 * (2 * 2000) ** 2 * 8 > 16 * 2 ** 30
-    eng = engine.Engine(fp)
+    eng = engine.Engine(fp, ordinary_group_elimination=FORCE)
     eng.set_parameters(fp.values)
     eng.build(s2, 0.0)
     assert eng.reduced_order() == U - 6 * fp.n_images
@@ -257,3 +261,19 @@ def test_a_large_ordinary_problem_is_eliminated_with_compact_weights():
     assert np.abs(dx - dxf).max() <= 1e-9 * np.abs(dxf).max()
     assert abs(om - full.omega(s2, dxf)) <= 1e-9 * om
     full.close()
+
+
+def test_default_eliminates_ordinary_images_only_where_it_saves_block_columns():
+    """Round 5's size rule (engine.hip, create): the default serves ordinary images as blocks when the 6 I exterior-orientation columns are
+    at least two 128-column blocks of the factorisation.  BASELINE config 2 (order 726 -> 606: six block columns -> five) stays at full
+    order -- its pass is 0.79 ms that way against 0.86 --, config 3 (3 614 -> 3 014: 29 -> 24) is eliminated, as is a block the size of
+    the bundled example (115 images: ten block columns -> four)."""
+    for name, want in (("cfg2", False), ("cfg3", True)):
+        fp = scene.config(name)
+        eng = engine.Engine(fp)
+        eng.set_parameters(fp.values)
+        eng.build(fp.sigma2apriori, 0.0)
+        U = fp.n_unknowns
+        assert ((U + 127) // 128 - (U - 6 * fp.n_images + 127) // 128 >= 2) == want
+        assert eng.reduced_order() == (U - 6 * fp.n_images if want else U), name
+        eng.close()

@@ -671,7 +671,7 @@ def test_config3_step_against_oracle(oracle_mod, factorisation, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("name", ["zernike_x", "zernike_y", "zernike_gradient", "zernike_mixed"])
+@pytest.mark.parametrize("name", ["zernike_x", "zernike_y", "zernike_gradient", "zernike_mixed", "zernike_high_x", "zernike_high_y", "zernike_example_gradient"])
 def test_zernike_rows_match_golden_and_oracle(oracle_mod, name):
     """Zernike X / Y / Gradient rows (ZernikeDistortionModelFactory.java:41-227) of the HIP kernel vs the oracle and vs the
     symbolic golden vectors (even radial orders)."""

@@ -230,6 +230,129 @@ def test_example_reduced_inversion_modes(H, example_base, mode):
     np.testing.assert_allclose(res[mode][1][:n], ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())   # two runs: atomics reorder sums
 
 
+def distortion_model_adjustment(H, base):
+    """ExampleDistortionModel.java:68-121 on the flat files: camera with the three Zernike models beside the .ior file's, c fixed at 28,
+    every radial coefficient fixed at 0, gradient model with the single indices 4, 12, 24, 40, 60 (Z_2^0 .. Z_10^0), REDUCED."""
+    T = H.DistortionModelType
+    pr = H.read_aicon_flat(base, [T.ZERNIKE_GRADIENT, T.ZERNIKE_X, T.ZERNIKE_Y])
+    cam = pr.camera
+    c = cam.getInteriorOrientation().getPrincipleDistance()
+    c.setValue(28.0); c.setColumn(H.COLUMN_FIXED)
+    for u in cam.getDistortionModel(T.RADIAL_DISTORTION).parameters():
+        u.setValue(0.0); u.setColumn(H.COLUMN_FIXED)
+    z = cam.getDistortionModel(T.ZERNIKE_GRADIENT)
+    order = 0
+    for i in range(1, 6):
+        order += 4 * i
+        z.add(order)
+    ba = H.BundleAdjustment()
+    ba.add(cam)
+    for s in pr.scaleBars():
+        ba.add(s)
+    ba.setInvertNormalEquation(H.MatrixInversion.REDUCED)
+    return pr, ba
+
+
+def test_third_example_index_contract_and_oracle(H, example_base, oracle_mod):
+    """The reference's third example (ExampleDistortionModel.java): what prepareUnknownParameters makes of it -- 450 point + 2 interior
+    (c fixed) + Cx, Cy, Bx, By (IORFileReader.java:95-206 sets what the .ior file carries free) + 5 Zernike gradient coefficients, A1..A3
+    fixed at 0, + 690 exterior = 1 151 unknowns, all 150 points in the datum (rank defect 6: the scale comes from the bar) -- and the CPU
+    oracle's run of it: converges, the Zernike set takes over what c = 28 (instead of 28.8) and the zeroed radial set leave, the
+    a-posteriori sigma0 stays where the radial model put it (x 1.5)."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    from bundle_adjustment_amd.problem import DIST_ZERNIKE_Z
+    pr, ba = distortion_model_adjustment(H, example_base)
+    ba.useCentroidedCoordinates(False)
+    ba.prepareUnknownParameters(); ba.flatten()
+    fp = flat_problem(ba).validate()
+    zs = [(int(k), int(o), int(c)) for k, o, c in zip(fp.dist_kind, fp.dist_order, fp.dist_col) if k == DIST_ZERNIKE_Z]
+    assert [o for _, o, _ in zs] == [4, 12, 24, 40, 60] and all(c >= 0 for _, _, c in zs)
+    from bundle_adjustment_amd.problem import DIST_RADIAL_AI
+    assert [int(c) for k, c in zip(fp.dist_kind, fp.dist_col) if k == DIST_RADIAL_AI] == [-1, -1, -1]      # A1, A2, A3 fixed (at 0)
+    assert all(int(c) >= 0 for k, c in zip(fp.dist_kind, fp.dist_col) if k not in (DIST_RADIAL_AI, DIST_ZERNIKE_Z))   # Cx, Cy, Bx, By stay free
+    assert int(fp.io_col[0][2]) == -1 and int(fp.io_col[0][0]) >= 0 and int(fp.io_col[0][1]) >= 0           # x0, y0 free, c fixed
+    assert fp.rank_defect == 6 and fp.n_unknowns - fp.rank_defect == 450 + 2 + 4 + 5 + 6 * 115
+    v, Q, res = oracle_mod.Oracle(fp).estimate(invert=2)                                           # MatrixInversion.REDUCED (BA:261-267)
+    assert res.state == 1 and res.iterations <= 12, (res.state, res.iterations)
+    s0 = np.sqrt(res.omega / fp.degree_of_freedom)
+    _, ba1 = example_adjustment(H, example_base)
+    ba1.useCentroidedCoordinates(False); ba1.prepareUnknownParameters(); ba1.flatten()
+    fp1 = flat_problem(ba1).validate()
+    _, _, r1 = oracle_mod.Oracle(fp1).estimate(invert=False)
+    s1 = np.sqrt(r1.omega / fp1.degree_of_freedom)
+    assert s0 < 1.5 * s1, (s0, s1)       # five radially symmetric Zernike terms describe this lens about as well as A1, A2 + B1, B2 did
+
+
+@pytest.mark.gpu
+def test_third_example_on_the_engine_matches_the_oracle(H, example_base, oracle_mod):
+    """the only reference-shipped configuration of this path the suite did not run.  estimateModel() of the host mirror
+    on the engine (EO pre-eliminated: reduced order U - 6 I) against the oracle's literal REDUCED run of the same flat problem: same pass
+    count, adjusted parameters 1e-9, Omega, the standard deviations of the five Zernike coefficients and of x0, y0, the point variances."""
+    from bundle_adjustment_amd.host_api import flat_problem
+    from bundle_adjustment_amd.problem import DIST_ZERNIKE_Z
+    pr0, ba0 = distortion_model_adjustment(H, example_base)
+    ba0.useCentroidedCoordinates(False)
+    ba0.prepareUnknownParameters(); ba0.flatten()
+    fp = flat_problem(ba0).validate()
+    vo, Qo, ro = oracle_mod.Oracle(fp).estimate(invert=2)
+    pr, ba = distortion_model_adjustment(H, example_base)
+    ba.useCentroidedCoordinates(False)
+    state = ba.estimateModel()
+    assert state == H.EstimationStateType.ERROR_FREE_ESTIMATION, ba.lastError()
+    assert ro.state == 1 and ba.getIterations() == ro.iterations
+    pts = ba.getObjectCoordinates()
+    got = np.array([[p.getX().getValue(), p.getY().getValue(), p.getZ().getValue()] for p in pts]).ravel()
+    ref = vo[:got.size]
+    assert (np.abs(got - ref) / np.maximum(np.abs(ref), 1.0)).max() < 1e-9
+    T = H.DistortionModelType
+    zern = pr.camera.getDistortionModel(T.ZERNIKE_GRADIENT)
+    zslots = [j for j, k in enumerate(fp.dist_kind) if k == DIST_ZERNIKE_Z]
+    base = 3 * fp.n_points + 3 * fp.n_cameras
+    for j, order in zip(zslots, (4, 12, 24, 40, 60)):
+        zv, zo = zern.get(order).getValue(), vo[base + j]
+        assert abs(zv - zo) <= 1e-9 * max(abs(zo), 1e-3), (order, zv, zo)
+    assert abs(ba.getOmega() - ro.omega) < 1e-8 * ro.omega
+    # cofactors: the leading numRows block (border, points, x0, y0, the five coefficients) of the reduced inverse
+    U, d = fp.n_unknowns, fp.rank_defect
+    k = U - 6 * fp.n_images
+    Q = packed_to_full(np.array(ba.getCofactorMatrix()), U)[:k, :k]
+    Qr = packed_to_full(Qo, U)[:k, :k]
+    cols = [int(fp.dist_col[j]) for j in zslots] + [int(fp.io_col[0][0]), int(fp.io_col[0][1])]
+    for c in cols:
+        assert d <= c < k
+        assert abs(Q[c, c] - Qr[c, c]) <= 1e-8 * Qr[c, c], (c, Q[c, c], Qr[c, c])
+    np.testing.assert_allclose(np.diag(Q)[d:], np.diag(Qr)[d:], rtol=1e-7)
+    sc = np.sqrt(np.abs(np.diag(Qr)[d:]))          # (the datum border's rows have no variances to scale by)
+    assert np.abs((Q[d:, d:] - Qr[d:, d:]) / np.outer(sc, sc)).max() < 1e-7
+
+
+@pytest.mark.gpu
+def test_native_example_distortion_model_program(example_base):
+    """bundle-adjustment_amd/host/example_distortion_model = ExampleDistortionModel.java as a native program on the engine: the
+    reference's listing (object points with uncertainties, interior orientation, every distortion parameter with `fixed` where it is, the
+    statistics block)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "bundle-adjustment_amd", "host", "example_distortion_model")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.dirname(exe), "example_distortion_model"])
+    out = subprocess.run([exe, example_base], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+    txt = out.stdout
+    assert "Bundle adjustment finished successfully..." in txt
+    assert "Number of observations:           19945" in txt and "Number of unknown parameters:     1151" in txt
+    assert "Degree of freedom:                18800" in txt
+    lines = txt.splitlines()
+    assert sum(1 for l in lines if l.rstrip().endswith("\to") or l.rstrip().endswith("\tn")) == 150     # one line per object point
+    assert any(l.startswith("PRINCIPAL_DISTANCE") and "+28.0000000000 fixed" in l for l in lines)
+    for order in (4, 12, 24, 40, 60):
+        row = [l for l in lines if l.startswith(f"ZERNIKE_POLYNOMIAL_Z({order})")]
+        assert len(row) == 1 and "fixed" not in row[0] and "+/-" in row[0], row
+    for a in (1, 2, 3):
+        row = [l for l in lines if l.startswith(f"RADIAL_POLYNOMIAL_A({a})")]
+        assert len(row) == 1 and "+0.0000000000 fixed" in row[0], row
+
+
 def test_zernike_models_in_the_object_api(H):
     """Camera with the three Zernike models next to the radial one (Camera.java:45-83 sorts the model types, DistortionModel
     ordinal = application order; ZernikeDistortionModel.java:36-60 parameter types): columns and flat descriptor."""

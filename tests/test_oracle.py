@@ -39,7 +39,7 @@ def test_rows_match_symbolic_golden(oracle_mod, name):
     assert worst < 1e-10, worst
 
 
-@pytest.mark.parametrize("name", ["zernike_x", "zernike_y", "zernike_gradient", "zernike_mixed"])
+@pytest.mark.parametrize("name", ["zernike_x", "zernike_y", "zernike_gradient", "zernike_mixed", "zernike_high_x", "zernike_high_y", "zernike_example_gradient"])
 def test_zernike_rows_match_symbolic_golden(oracle_mod, name):
     """ZernikeDistortionModelFactory.java:41-227 restated in the oracle vs sympy/mpmath derivatives of
     dx = z Z(xs, ys) (X), dy = z Z (Y), (dx, dy) = z grad Z (Gradient) for polynomials of even radial order
