@@ -31,4 +31,8 @@ struct BatchedSpdInverse {
     hipError_t run(int count);
 };
 
+// One Newton-Schulz step Q <- Q + sym(Q (I - M Q)) with the residual formed exactly (batchinv.hip), for ONE matrix of order n <= 8192
+// (multiple of 128): M, Q full symmetric squares, leading dimension ld; M is destroyed; W, T1, T2, T3 are n x ld work squares.
+hipError_t newton_schulz_exact(hipStream_t stream, int n, long ld, double *M, double *Q, double *W, double *T1, double *T2, double *T3);
+
 }  // namespace jaicov

@@ -68,13 +68,18 @@ constexpr int SLICE_BITS = 20;
 __global__ __launch_bounds__(256) void slice_rows_kernel(const double *src, double *hi, double *lo, long ld, long msz, int mp) {
     __shared__ double red[256];
     const long base = (long)blockIdx.y * msz + (long)blockIdx.x * ld;
-    double v[8];                       // mp <= 2048
+    double v[8];                       // mp <= 2048: the row stays in registers; longer rows (the solver's inverse, below) are read twice
+    const bool cached = mp <= 2048;
     double mx = 0.0;
+    if (cached) {
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int j = threadIdx.x + 256 * t;
-        v[t] = j < mp ? src[base + j] : 0.0;
-        mx = fmax(mx, fabs(v[t]));
+        for (int t = 0; t < 8; t++) {
+            const int j = threadIdx.x + 256 * t;
+            v[t] = j < mp ? src[base + j] : 0.0;
+            mx = fmax(mx, fabs(v[t]));
+        }
+    } else {
+        for (int j = threadIdx.x; j < mp; j += 256) mx = fmax(mx, fabs(src[base + j]));
     }
     red[threadIdx.x] = mx;
     __syncthreads();
@@ -86,13 +91,22 @@ __global__ __launch_bounds__(256) void slice_rows_kernel(const double *src, doub
     int ex = 0;
     (void)frexp(mx, &ex);              // mx = f 2^ex, f in [0.5, 1): every |entry| <= mx < 2^ex
     const double unit = ldexp(1.0, ex - SLICE_BITS), inv_unit = ldexp(1.0, SLICE_BITS - ex);
+    if (cached) {
 #pragma unroll
-    for (int t = 0; t < 8; t++) {
-        const int j = threadIdx.x + 256 * t;
-        if (j < mp) {
-            const double h = mx > 0.0 ? rint(v[t] * inv_unit) * unit : 0.0;
+        for (int t = 0; t < 8; t++) {
+            const int j = threadIdx.x + 256 * t;
+            if (j < mp) {
+                const double h = mx > 0.0 ? rint(v[t] * inv_unit) * unit : 0.0;
+                hi[base + j] = h;
+                lo[base + j] = v[t] - h;
+            }
+        }
+    } else {                           // (every thread reads and writes its own entries only: hi / lo may alias src here too)
+        for (int j = threadIdx.x; j < mp; j += 256) {
+            const double x = src[base + j];
+            const double h = mx > 0.0 ? rint(x * inv_unit) * unit : 0.0;
             hi[base + j] = h;
-            lo[base + j] = v[t] - h;
+            lo[base + j] = x - h;
         }
     }
 }
@@ -216,6 +230,34 @@ hipError_t BatchedSpdInverse::run(int count) {
     HIPCHK(prod(Db, Qb, LAY_XC, S2, -1.0, 1.0));           // R -= D2 X
     HIPCHK(prod(Qb, S2, LAY_XC, Lb, 1.0, 0.0));            // Y = X R
     hipLaunchKernelGGL(newton_update_kernel, ge, dim3(256), 0, stream, Qb, Lb, ld, msz, mp);
+    return hipGetLastError();
+}
+
+
+// The same step for ONE matrix of order n <= 8192 (20 + 20 bits + log2(n) <= 53: the product of the leading slices is still exact): the inverse
+// Q of the solver's scaled matrix M (engine.hip, solve with an inverse; round 5).  An inverse formed from a Cholesky factor at cond(M) ~ 4e8
+// (BASELINE config 3) is 2-3e-9 from the exact inverse, correlation-scaled, where the reference's dspsv + dsptri reaches 5e-10
+// (tests/golden/cfg3/cfg3_exactN.json): north_star's 1e-9 on the covariances was missed by that factor.  One step with the exact residual
+// takes it to the rounding of Q's entries.
+//   M, Q: FULL symmetric squares (leading dimension ld); M is destroyed (becomes its low slice), W, T1, T2, T3: n x ld work squares.
+hipError_t newton_schulz_exact(hipStream_t stream, int n, long ld, double *M, double *Q, double *W, double *T1, double *T2, double *T3) {
+    if (n <= 0 || n % 128 != 0 || n > 8192) return hipErrorInvalidValue;
+    const long msz = (long)n * ld;
+    const dim3 gr(n, 1), ge((n + 255) / 256, n, 1);
+    hipLaunchKernelGGL(slice_rows_kernel, gr, dim3(256), 0, stream, M, T1, M, ld, msz, n);        // D1 -> T1, D2 -> M (in place)
+    hipLaunchKernelGGL(slice_rows_kernel, gr, dim3(256), 0, stream, Q, W, T2, ld, msz, n);        // X1' -> W, X2' -> T2 (rows of the symmetric X)
+    auto prod = [&](const double *A, const double *B, int blay, double *C, double alpha, double beta) -> hipError_t {
+        GemmArgs g{};
+        g.A = A; g.lda = ld; g.B = B; g.ldb = ld; g.C = C; g.ldc = ld;
+        g.M = n; g.N = n; g.K = n; g.alpha = alpha; g.beta = beta; g.kmode = KMODE_FULL;
+        return gemm_f64(stream, LAY_KC, blay, g);
+    };
+    HIPCHK(prod(T1, W, LAY_KC, T3, 1.0, 0.0));             // T = D1 X1, exact
+    hipLaunchKernelGGL(eye_minus_kernel, ge, dim3(256), 0, stream, T3, ld, msz, n);
+    HIPCHK(prod(T1, T2, LAY_KC, T3, -1.0, 1.0));           // R -= D1 X2
+    HIPCHK(prod(M, Q, LAY_XC, T3, -1.0, 1.0));             // R -= D2 X
+    HIPCHK(prod(Q, T3, LAY_XC, T1, 1.0, 0.0));             // Y = X R
+    hipLaunchKernelGGL(newton_update_kernel, ge, dim3(256), 0, stream, Q, T1, ld, msz, n);        // X += (Y + Y') / 2
     return hipGetLastError();
 }
 

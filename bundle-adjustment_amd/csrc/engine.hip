@@ -199,6 +199,8 @@ struct jaicov_engine {
     std::string err = "";
     int device = 0;
     int flow_retries = 0;      // dataflow factorisations that were abandoned and repeated (solve)
+    double *ns_work = nullptr; // three squares of the inverse's Newton-Schulz step (orders <= 8192, option inverse_refinement)
+    size_t ns_work_len = 0;
     int refine_steps = 1;      // iterative refinement of the step (refine.hip): engine option `refinement` / JAICOV_REFINE
     double *d_Braw = nullptr, *d_refP = nullptr, *d_ref = nullptr;   // unscaled datum rows; partial-sum table; rhs | tmp | delta
     size_t refP_len = 0;
@@ -485,6 +487,7 @@ extern "C" void jaicov_neq_destroy(jaicov_engine *e) {
     if (e->ev_r1) hipEventDestroy(e->ev_r1);
     if (e->d_refP) hipFree(e->d_refP);
     if (e->d_expF) hipFree(e->d_expF);
+    if (e->ns_work) hipFree(e->ns_work);
     jaicov::stream_release(jaicov::STREAM_PLAIN, e->stream);
     delete e;
 }
@@ -1605,6 +1608,24 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         // (MatrixInversion.REDUCED / PRE_ELIMINATION, BA:261-267: solve(N, n, numRows, true) on the reduced system).
         HIPE(e, slv.trtri());
         HIPE(e, slv.lauum());
+        if (e->opts.inverse_refinement >= 0 && Up <= 8192) {
+            // One Newton-Schulz step on Q = inv(M) with the residual I - M Q formed exactly (batchinv.hip): M is materialised once more
+            // (scaled, with the datum border's term; the factor in slv.L is not needed again before the next factorisation), W is free
+            // after lauum(), three more squares are kept with the engine.
+            const size_t sq = (size_t)Up * ld;
+            if (e->ns_work_len < 3 * sq) {
+                if (e->ns_work) hipFree(e->ns_work);
+                e->ns_work = nullptr; e->ns_work_len = 0;
+                HIPE(e, hipMalloc(&e->ns_work, 3 * sq * sizeof(double)));
+                e->ns_work_len = 3 * sq;
+            }
+            HIPE(e, slv.begin_refactor());
+            HIPE(e, slv.symmetrize(slv.Q));
+            hipLaunchKernelGGL(scale_copy_kernel, dim3((Up + 255) / 256, Up), dim3(256), 0, e->stream, e->d_N, (long)Upad, slv.L, ld, U,
+                               Up, d, e->d_V, e->d_B, Upad, 0, Up);
+            HIPE(e, slv.symmetrize(slv.L));
+            HIPE(e, newton_schulz_exact(e->stream, Up, ld, slv.L, slv.Q, slv.W, e->ns_work, e->ns_work + sq, e->ns_work + 2 * sq));
+        }
         // H = Sinv G^ ; F = R (Sinv G^) V ; E = R (I - Sinv) R
         std::vector<double> H((size_t)8 * Upad, 0.0), F((size_t)8 * Upad, 0.0);
         double E[49];
@@ -1691,6 +1712,7 @@ extern "C" int jaicov_neq_expansion_buffer(jaicov_engine *e, void **device_ptr, 
     const size_t len = I6p * Up + (size_t)36 * e->p.n_images;
     if (!e->d_expF || e->expF_len != len) {
         if (e->d_expF) hipFree(e->d_expF);
+    if (e->ns_work) hipFree(e->ns_work);
         e->d_expF = nullptr;
         HIPE(e, hipMalloc(&e->d_expF, len * sizeof(double)));
         e->expF_len = len;

@@ -50,7 +50,7 @@ class EngineOptions(C.Structure):
                 ("image_end", C.c_int32), ("apply_shared", C.c_int32), ("assembly_mode", C.c_int32),
                 ("block_size", C.c_int32), ("reduced_reference_quirk", C.c_int32), ("deterministic", C.c_int32), ("refinement", C.c_int32),
                 ("ordinary_group_elimination", C.c_int32), ("dispersion_refinement", C.c_int32),
-                ("expansion_exchange", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("expansion_exchange", C.c_int32), ("inverse_refinement", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class EstimateOptions(C.Structure):
@@ -136,7 +136,8 @@ class Engine:
 
     def __init__(self, fp: FlatProblem, device: int = 0, image_range=None, apply_shared: bool = True, assembly_mode: int = 0,
                  reduced_reference_quirk: bool = False, deterministic=None, refinement: int = 0,
-                 ordinary_group_elimination: int = 0, dispersion_refinement: int = 0, expansion_exchange: bool = False):
+                 ordinary_group_elimination: int = 0, dispersion_refinement: int = 0, expansion_exchange: bool = False,
+                 inverse_refinement: int = 0):
         self.L = load_library()
         self.fp = fp
         self.U = fp.n_unknowns
@@ -154,6 +155,7 @@ class Engine:
         opts.dispersion_refinement = int(dispersion_refinement)             # < 0: inv(D) as the blocked Cholesky leaves it
         opts.expansion_exchange = int(expansion_exchange)                   # sharded engines: the caller all-reduces expansion_buffer()
         self.expansion_exchange = bool(expansion_exchange)
+        opts.inverse_refinement = int(inverse_refinement)                   # < 0: no Newton-Schulz step on the inverse of orders <= 8192
         opts.refinement = int(refinement)      # 0 = default (one step of iterative refinement per solve), < 0 = none, k = k steps
         self._h = C.c_void_p()
         rc = self.L.jaicov_neq_create(C.byref(self._desc), C.byref(opts), C.byref(self._h))

@@ -188,7 +188,13 @@ typedef struct jaicov_engine_options {
                                       jaicov_neq_expansion_buffer() over the ranks between accumulate and the inverting solve, so that
                                       MatrixInversion.FULL is expanded from the reduced inverse on a shard too (JAICOV_INVERT_FULL_EXPANDED;
                                       without the promise a shard falls back to the literal order-U route).  Ignored on an unsharded engine. */
-    int32_t  reserved[2];
+    int32_t  inverse_refinement;   /* 0 = default: an inverting solve of order <= 8192 (padded) adds one Newton-Schulz step Q <- Q + Q (I - M Q) to the
+                                      inverse of the scaled system, with the residual formed exactly by error-free splitting on the fp64 matrix
+                                      cores (batchinv.hip): the inverse from a Cholesky factor at cond ~ 4e8 (BASELINE config 3) is 2-3e-9 from the
+                                      exact inverse where the reference's dspsv + dsptri reaches 5e-10; with the step it is at the rounding of its
+                                      entries.  Four GEMMs of the order (+4 ms at config 3, once per adjustment).  Larger orders are left alone: at
+                                      config 4 the reference itself is 2e-7 from the truth, the engine 2e-8.  < 0: off.    */
+    int32_t  reserved[1];
 } jaicov_engine_options;
 
 typedef struct jaicov_engine jaicov_engine;

@@ -82,7 +82,8 @@ static int read_options(JNIEnv *e, jobject opt, jaicov_engine_options *o) {
         {"refinement", offsetof(jaicov_engine_options, refinement)},
         {"ordinaryGroupElimination", offsetof(jaicov_engine_options, ordinary_group_elimination)},
         {"dispersionRefinement", offsetof(jaicov_engine_options, dispersion_refinement)},
-        {"expansionExchange", offsetof(jaicov_engine_options, expansion_exchange)}};
+        {"expansionExchange", offsetof(jaicov_engine_options, expansion_exchange)},
+        {"inverseRefinement", offsetof(jaicov_engine_options, inverse_refinement)}};
     for (size_t q = 0; q < sizeof(I) / sizeof(I[0]); q++) {
         jfieldID f = (*e)->GetFieldID(e, oc, I[q].name, "I");
         if (!f) return -1;

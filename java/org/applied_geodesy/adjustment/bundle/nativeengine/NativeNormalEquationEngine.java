@@ -50,6 +50,8 @@ public final class NativeNormalEquationEngine implements AutoCloseable {
 		public int dispersionRefinement = 0;
 		/** != 0 on a sharded engine: the host sums expansionBuffer() over the ranks before an inverting solve with invert = 3 */
 		public int expansionExchange = 0;
+		/** < 0: no Newton-Schulz step on the inverse of systems of order <= 8192 (the step takes Qxx from 3e-9 to 1e-12 of the exact inverse at config 3) */
+		public int inverseRefinement = 0;
 
 		/** the options BundleAdjustment.native.patch reads from system properties, next to org.applied_geodesy.adjustment.bundle.native */
 		public static EngineOptions fromSystemProperties() {

@@ -2,6 +2,7 @@
 """GROUND TRUTH for the accuracy of the cofactor matrix: the normal equations assembled in extended precision ("exact N") and
 their exact solution / inverse columns, at the parameter values of the oracle fixtures.
 
+    python tests/golden/make_exactN.py cfg3 converged       (~1 min; round 5: config 3 proper, ordinary 2 x 2 weights)
     python tests/golden/make_exactN.py cfg3b converged      (~2 min, 8 threads)
     python tests/golden/make_exactN.py cfg4 converged       (~25 min, 8 threads, ~12 GB)
     python tests/golden/make_exactN.py cfg4 pass2
@@ -53,7 +54,7 @@ def unpack_lower(ap, U, scale=None):
 
 def main():
     cfg, point = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "converged")
-    scene_name = {"cfg3b": "cfg3_block", "cfg4": "cfg4"}[cfg]
+    scene_name = {"cfg3": "cfg3", "cfg3b": "cfg3_block", "cfg4": "cfg4"}[cfg]
     out_dir = os.path.join(HERE, cfg)
     orc.build()
     L = orc.lib()
@@ -89,6 +90,12 @@ def main():
     if nkey in z.files and vkey in z.files:            # the fixture holds the oracle's n and N.v of this pass
         no, Nvo = z[nkey], z[vkey]
         wts = {b: o.block_weight(s2, b) for b in range(min(4, fp.n_image_blocks))}
+    elif fp.n_image_blocks == 0:                       # ordinary image groups only (config 3 proper): the oracle's literal stacking (PDF:475-505)
+        No, no, _ = o.build(values, s2, 0.0)
+        wts = {}
+        Nvo = g.packed_matvec(No, probe)
+        meta["oracle_N_err_max_entry"] = float(np.abs(No - Nh).max() / np.abs(Nh).max())
+        del No
     else:
         with cf.ThreadPoolExecutor(max_workers=6) as ex:
             wts = dict(enumerate(ex.map(lambda b: o.block_weight(s2, b), range(fp.n_image_blocks))))
