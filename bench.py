@@ -424,6 +424,29 @@ def main():
         out["create_ms"]["wall_second_engine"] = 1e3 * (time.perf_counter() - t_c)
         out["create_ms"]["second_engine"] = e2.create_timings()
         e2.close()
+    if rank == 0 and world == 1 and not use_dist and not a.iterations_only and a.config == "cfg4" and not os.environ.get("JAICOV_BENCH_NO_LOCAL_SCENE"):
+        # The same stage on a scene WITH spatial locality (scene.config("cfg4_local"): config 4's size and stochastic model on a block flown in
+        # strips, first-seen numbering -- the shape of real photogrammetric blocks, and of the bundled example): the random-visibility
+        # BASELINE scene is the kind case for the point x point gather.  Reported, not `value`.
+        try:
+            fpl = scene.config("cfg4_local")
+            el = engine.Engine(fpl, device=local)
+            el.set_parameters(fpl.values)
+            acc = {}
+            for it in range(6):
+                el.build(fpl.sigma2apriori, 0.0)
+                dxl = el.solve(False)
+                if it >= 2:
+                    for k, v in el.timings().items():
+                        acc[k] = acc.get(k, 0.0) + v / 4.0
+            out["assembly_ms_local_scene"] = acc.get("assembly")
+            out["local_scene"] = {"workload": f"cfg4_local: {fpl.n_images} images x {fpl.n_points} points in strips, {fpl.n_image_points} image points, U={fpl.n_unknowns}",
+                                  "stage_ms_per_step": acc, "gather_strip_columns": el.kernel_stats().get("gather_strip_columns")}
+            el.close()
+            del fpl
+        except Exception as ex:      # the line must not die on the extra scene
+            out["assembly_ms_local_scene"] = None
+            out["local_scene"] = {"error": str(ex)}
     if rank == 0:
         if not a.no_cpu_baseline and not a.iterations_only:
             out["cpu_baseline"] = cpu_baseline(fp, eng, s2)

@@ -42,6 +42,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <chrono>
@@ -1087,6 +1088,111 @@ bool DenseSolver::flow_kernels_overlap() {
     return cached != 0;
 }
 
+// ---- residency of the tile kernel beside the chain workgroups, MEASURED (round 5) -----------------------------------------------------
+// The `keep` rule of potrf_flow (the last workgroups dealt to an XCD that hosts a chain workgroup leave without a ticket, so that the ones
+// queued behind its full shader engine get in and leave too) used to assume the MI355X's shape: 8 XCDs x 4 shader engines, 64 blocks dealt
+// per XCD, "the last eight".  It is now derived from what a launch of the tile kernel's footprint actually does next to stand-ins of the
+// chain workgroups: XCDs seen, shader engines per XCD, blocks dealt to an XCD, and how many of them stay QUEUED on an XCD whose reserved CU
+// is taken.  Once per process and (grid, chain workgroups).
+struct FlowResidency { int n_xcd = 0, n_se = 0, dealt = 0, resident_min = 0, queued_max = 0, keep = 0, se_cap = 0; bool valid = false; };
+
+__global__ __launch_bounds__(256) void flow_residency_standin_kernel(int *alive, const int *release) {
+    __shared__ double S[128 * DP];                 // the chain kernel's LDS: a whole CU
+    __shared__ double Wd[8 * 16 * WDP];
+    S[threadIdx.x] = 0.0; Wd[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(alive + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < 20000000LL) __builtin_amdgcn_s_sleep(100);
+        if (S[1] + Wd[1] != 0.0) alive[0] = 2;     // (keeps the arrays)
+    }
+}
+// counts: [0..15] workgroups that started before the release (resident at once), [16..31] workgroups dealt, [32..47] highest shader-engine id, per XCC;
+// [64 + 8 xcc + se] resident at once per shader engine
+__global__ __launch_bounds__(256, 2) void flow_residency_probe_kernel(int *counts, const int *release) {
+    __shared__ double smem[2 * FLOW_STAGE];        // the tile kernel's LDS: two workgroups per CU
+    smem[threadIdx.x] = 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int xcc = (int)(__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
+        const int se = (int)((__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) >> 13) & 7);
+        const bool early = __hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0;
+        if (early) { atomicAdd(counts + xcc, 1); atomicAdd(counts + 64 + 8 * xcc + se, 1); }
+        atomicAdd(counts + 16 + xcc, 1);
+        atomicMax(counts + 32 + xcc, se);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0 && wall_clock64() - t0 < 20000000LL) __builtin_amdgcn_s_sleep(100);
+        if (smem[1] != 0.0) counts[48] = 1;
+    }
+}
+
+static FlowResidency flow_measure_residency(hipStream_t stream, hipStream_t dstream, int grid, int chain_wgs) {
+    static std::vector<std::pair<std::pair<int, int>, FlowResidency>> cache;
+    for (auto &c : cache)
+        if (c.first == std::make_pair(grid, chain_wgs)) return c.second;
+    FlowResidency r;
+    int *host = nullptr, *counts = nullptr;
+    int h[192] = {0};
+    bool ok = hipHostMalloc((void **)&host, 8 * sizeof(int), hipHostMallocMapped) == hipSuccess && hipMalloc(&counts, 192 * sizeof(int)) == hipSuccess &&
+              hipMemset(counts, 0, 192 * sizeof(int)) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+    if (ok) {
+        for (int i = 0; i < 8; i++) host[i] = 0;
+        hipLaunchKernelGGL(flow_residency_standin_kernel, dim3(chain_wgs), dim3(256), 0, dstream, host, host + 4);
+        const auto t0 = std::chrono::steady_clock::now();
+        auto alive = [&]() { for (int i = 0; i < chain_wgs; i++) if (__atomic_load_n(host + i, __ATOMIC_ACQUIRE) == 0) return false; return true; };
+        while (!alive() && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1.0) std::this_thread::yield();
+        ok = alive();
+        if (ok) {
+            hipLaunchKernelGGL(flow_residency_probe_kernel, dim3(grid), dim3(256), 0, stream, counts, host + 4);
+            std::this_thread::sleep_for(std::chrono::milliseconds(3));      // every workgroup that fits has started and counted itself
+        }
+        __atomic_store_n(host + 4, 1, __ATOMIC_RELEASE);
+        ok = hipStreamSynchronize(stream) == hipSuccess && hipStreamSynchronize(dstream) == hipSuccess && ok &&
+             hipMemcpy(h, counts, 192 * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (host) hipHostFree(host);
+    if (counts) hipFree(counts);
+    if (ok) {
+        int full = 0;
+        for (int x = 0; x < 16; x++)
+            if (h[16 + x] > 0) { r.n_xcd++; r.dealt = std::max(r.dealt, h[16 + x]); r.n_se = std::max(r.n_se, h[32 + x] + 1); full = std::max(full, h[x]); }
+        r.resident_min = full;
+        for (int x = 0; x < 16; x++)
+            if (h[16 + x] > 0) { r.resident_min = std::min(r.resident_min, h[x]); r.queued_max = std::max(r.queued_max, h[16 + x] - h[x]); }
+        // the rule: of the blocks dealt to an XCD that hosts a chain workgroup, the last  max(2 per shader engine, the queued ones + one per
+        // further shader engine)  leave at once -- on the MI355X 8 of 64 (5 queued, 4 shader engines), i.e. keep = 448 of 512, the value the
+        // soaks of rounds 3-5 ran with.  Nothing queued anywhere (another device shape, another footprint): no rule.
+        const int leave = r.queued_max > 0 ? std::max(2 * r.n_se, r.queued_max + r.n_se - 1) : 0;
+        r.keep = leave > 0 && r.n_xcd > 0 && grid % r.n_xcd == 0 && r.dealt > leave ? r.n_xcd * (r.dealt - leave) : 0;
+        r.se_cap = 1 << 30;      // fewest workgroups resident at once on one shader engine (the one whose CU a chain workgroup holds)
+        for (int x = 0; x < 16; x++)
+            for (int q = 0; q < r.n_se; q++)
+                if (h[16 + x] > 0) r.se_cap = std::min(r.se_cap, h[64 + 8 * x + q]);
+        r.valid = true;
+    }
+    (void)hipGetLastError();
+    if (getenv("JAICOV_VERBOSE"))
+        fprintf(stderr, "jaicov: residency of the tile kernel beside %d chain workgroups (grid %d): %s; %d XCDs, %d shader engines each, %d blocks dealt per XCD, "
+                "at least %d resident at once (%d on the fullest-booked shader engine), at most %d queued -> blocks >= %d of a chain workgroup's XCD leave without a ticket\n",
+                chain_wgs, grid, r.valid ? "measured" : "NOT measured", r.n_xcd, r.n_se, r.dealt, r.resident_min, r.se_cap, r.queued_max, r.keep);
+    cache.push_back({{grid, chain_wgs}, r});
+    return r;
+}
+extern "C" int jaicov_debug_flow_residency(int *out8) {       // tests / DESIGN.md: {valid, XCDs, shader engines, dealt, resident min, queued max, keep, 0}
+    hipStream_t s = nullptr, d = stream_acquire(STREAM_DIAGONAL_CUS);
+    if (!d || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return -1;
+    int cus = 256;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const FlowResidency r = flow_measure_residency(s, d, std::min(1024, 2 * cus), 2);
+    hipStreamDestroy(s);
+    stream_release(STREAM_DIAGONAL_CUS, d);
+    out8[0] = r.valid; out8[1] = r.n_xcd; out8[2] = r.n_se; out8[3] = r.dealt; out8[4] = r.resident_min; out8[5] = r.queued_max; out8[6] = r.keep; out8[7] = r.se_cap;
+    return 0;
+}
+
 hipError_t DenseSolver::flow_init() {
     const int nb = nfact / 128, row_blocks = n / 128;
     if (!dstream) return hipErrorNotSupported;
@@ -1144,6 +1250,7 @@ hipError_t DenseSolver::flow_init() {
     HIPCHK(hipEventCreateWithFlags(&flow_e1, hipEventDisableTiming));
     HIPCHK(hipEventCreate(&flow_t0));
     HIPCHK(hipEventCreate(&flow_t1));
+    flow_keep = flow_chain ? flow_measure_residency(stream, dstream, flow_grid, flow_second ? 3 : 2).keep : 0;
     flow_ready = true;
     if (getenv("JAICOV_FLOW_TRACE_ON")) HIPCHK(flow_enable_trace(true));     // per-task timestamps, read by flow_report_stall
     return hipSuccess;
@@ -1195,15 +1302,9 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     g.crit_prio = 1;
     g.second_update = flow_second >= 2 ? 1 : 0;
     g.second_wg = flow_second ? 1 : 0;
-    // "the last eight workgroups of every XCD" presumes the grid the observation was made with: two workgroups per CU dealt
-    // round-robin to eight XCDs.  Any other device shape keeps every workgroup: the rule would pick the wrong ones.
-    {
-        int cus = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        const bool standard_grid = cus > 0 && cus % 8 == 0 && flow_grid == 2 * cus && flow_grid / 8 > 8;
-        g.keep = flow_chain && standard_grid ? 8 * (flow_grid / 8 - 8) : 0;
-    }
+    // which of the last workgroups of a chain workgroup's XCD take no ticket: from the residency measured beside stand-ins of the chain
+    // workgroups (flow_measure_residency; 448 of 512 on the MI355X), 0 = none (nothing stays queued on this device, or not measurable)
+    g.keep = flow_chain ? flow_keep : 0;
     g.inv_wt = 1;
     g.crit_span = flow_chain ? 2 : 1;
     g.alive = flow_alive;

@@ -79,6 +79,7 @@ struct DenseSolver {
     int reserved_cus = 8;                // CUs kept free of the update stream for the diagonal-block kernel
     int4 *flow_task_list = nullptr;
     int flow_tasks = 0, flow_fs = 0, flow_grid = 0;
+    int flow_keep = 0;                   // blocks >= this on an XCD that hosts a chain workgroup take no ticket (measured at flow_init, cholflow.hip)
     int *flow_flags = nullptr;           // control words, done / applied flags, diag_ready
     size_t flow_words = 0;
     double *flow_scratch = nullptr;

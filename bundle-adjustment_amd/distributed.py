@@ -64,11 +64,12 @@ def allreduce_engine_buffer(eng, dist, device):
         with torch.cuda.stream(ext):
             buf = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
             dist.all_reduce(buf)
-        return
+        return ext
     ptr, cnt = eng.reduce_buffer()
     buf = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
     dist.all_reduce(buf)
     torch.cuda.synchronize(device)
+    return None
 
 
 def _check_same_buffer_on_all_ranks(eng, dist, device):
@@ -97,15 +98,21 @@ def sharded_step(eng, dist, device, sigma2, lam=0.0, invert=False):
     eng.prepare_inverse(invert)
     eng.accumulate(sigma2, lam)
     _check_same_buffer_on_all_ranks(eng, dist, device)
-    allreduce_engine_buffer(eng, dist, device)
+    ext = allreduce_engine_buffer(eng, dist, device)
     if int(invert) == 3 and getattr(eng, "expansion_exchange", False) and eng.reduced_order() < eng.U:
         # MatrixInversion.FULL expanded from the reduced inverse (BA:268-271): every rank holds the F bands and L_E^-1 of its own
-        # images only; one more all-reduce (zeros elsewhere) gives every rank all of them (371 MB at config 4)
+        # images only; one more all-reduce (zeros elsewhere) gives every rank all of them (371 MB at config 4).  Like the first
+        # collective it is enqueued in the order of the engine's own stream when the backend is RCCL (round 5: it used to run on torch's
+        # stream behind a device-wide synchronisation): finalize and the solve follow it on that stream, the host does not wait.
         ptr, cnt = eng.expansion_buffer()
         t = torch.as_tensor(DeviceArray(ptr, cnt), device=device)
-        dist.all_reduce(t)
-        if torch.device(device).type == "cuda":
-            torch.cuda.synchronize(device)
+        if ext is not None:
+            with torch.cuda.stream(ext):
+                dist.all_reduce(t)
+        else:
+            dist.all_reduce(t)
+            if torch.device(device).type == "cuda":
+                torch.cuda.synchronize(device)
     eng.finalize(sigma2, lam)
     dx = eng.solve(invert)
     e0 = eng.reduced_order()

@@ -146,6 +146,22 @@ def test_factor_tile_by_tile_at_the_orders_between(n):
     np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-11)
 
 
+def test_keep_rule_is_derived_from_measured_residency():
+    """Round 5: which of the tile kernel's last workgroups take no ticket is no longer "the last eight of every XCD of an
+    8 x 32 x 2 grid" but follows from a residency measurement beside stand-ins of the chain workgroups (cholflow.hip,
+    flow_measure_residency): XCDs and shader engines seen, blocks dealt per XCD, how many of them stay queued where a CU is taken."""
+    import ctypes as C
+    lib = engine.load_library()
+    out = (C.c_int * 8)()
+    assert lib.jaicov_debug_flow_residency(out) == 0
+    valid, n_xcd, n_se, dealt, resident, queued, keep, _ = list(out)
+    assert valid == 1 and n_xcd >= 1 and n_se >= 1 and dealt >= resident > 0 and queued == dealt - resident
+    leave = max(2 * n_se, queued + n_se - 1) if queued > 0 else 0
+    assert keep == (n_xcd * (dealt - leave) if leave and dealt > leave else 0)
+    if (n_xcd, n_se, dealt) == (8, 4, 64):          # the MI355X: 59 of 64 resident on an XCD whose reserved CU is taken (15 + 15 + 15 + 14), 5 queued
+        assert (resident, queued, keep) == (59, 5, 448)
+
+
 def test_dense_not_spd_reports_singular():
     S = -np.eye(130)
     with pytest.raises(engine.EngineError) as ei:
