@@ -302,9 +302,9 @@ def main():
         # library (csrc/kernel_resources.json, written by the Makefile)
         try:
             kr = json.load(open(os.path.join(ROOT, "bundle-adjustment_amd", "csrc", "kernel_resources.json")))
-            # (blk_pp_gather_kernel<true, true, false>: the deterministic assembly (the default), <true, false, false> the arrival-order form; chol_tile_kernel<1, true>: the one-kernel form the PMC counters
+            # (blk_pp_gather_kernel<true, true, false, true>: the deterministic assembly (the default; pass-major since round 5), <true, false, false, false> the arrival-order form; chol_tile_kernel<1, true>: the one-kernel form the PMC counters
             # are collected on -- not kernels of the default LM pass, listed because figures of this line's family quote them)
-            lm = ("chol_tile_kernel<1, false>", "chol_tile_kernel<1, true>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false, false>", "blk_pp_gather_kernel<true, true, false>", "blk_T_mfma_kernel", "blk_elim_kernel",
+            lm = ("chol_tile_kernel<1, false>", "chol_tile_kernel<1, true>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false, false", "blk_pp_gather_kernel<true, true, false", "blk_T_mfma_kernel", "blk_elim_kernel",
                   "blk_tfix_kernel", "blk_cc", "blk_pc_gather", "rows_kernel", "backsolve_chain8_kernel", "forwardsolve_chain8_kernel", "forwardsolve_chain_kernel", "gemm_f64_kernel<0, 1, 128, 128, 0>",
                   "symv_dd_tile_kernel", "symv_dd_reduce_kernel", "blk_backsub_kernel", "damp_and_precond_kernel")
             tab = {}

@@ -663,7 +663,7 @@ __device__ __forceinline__ int2 pp_range(const int2 *range, long idx) {
     return make_int2(__builtin_amdgcn_readfirstlane(g.x), __builtin_amdgcn_readfirstlane(g.y));
 }
 
-template <bool FUSED, bool DET = false, bool MIXED = false>
+template <bool FUSED, bool DET = false, bool MIXED = false, bool PASSES = false>
 __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, PPGather pp, const double *__restrict__ rowsA,
                                                             const double *__restrict__ Ubuf, double sigma2, double *__restrict__ N) {
     extern __shared__ double strip[];              // 3 rows x cw columns, + one word (DET: the turn, see below)
@@ -710,6 +710,8 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     // (Measured alternatives of round 3, all slower at config 4: loads without the else branch 3.2-3.6 ms -- the compiler then keeps old
     // and new contents of the operand registers alive and spills --, unconditional loads from clamped indices 3.3-3.7, two operand sets
     // used alternately instead of the copy 3.6.)
+    // (Round 5: the instance the default pass runs -- FUSED, deterministic, dense blocks only -- deals SEGMENTS pass by pass instead, see
+    // PASSES above; what follows is the image-major loop of the arrival-order form and of the MIXED / unfused deterministic instances.)
     // DETERMINISTIC form (the default): the ADDS into the strip happen in image order.  A wave forms the products of its segment
     // (pp_products: everything up to the 18 multiplications by A_p) while earlier images are still being added, waits for its image's
     // turn -- a sequence word in LDS that counts the images of this point that have been added --, issues its LDS adds (all segments
@@ -718,6 +720,97 @@ __global__ __launch_bounds__(PP_NT, 4) void blk_pp_gather_kernel(DevProblem p, P
     // serialised inside a workgroup.  (Round 3's form let the waves add in turn with a workgroup barrier after every turn, the products
     // formed inside the turn: +0.7 ms per pass at config 4; round 2's walked all images with every wave: +1.7 ms; this one +0.3.  All
     // three sum in image order: identical bits.)
+    if constexpr (PASSES) {
+        // PASS-MAJOR distribution (round 5).  The unit of work is a SEGMENT of 64 partners; the segments of this (point, chunk) are ordered
+        // (window of 64 images, segment number s inside its image, image) and dealt to the waves in turn, the deterministic form adds them in
+        // exactly that order (the turn word counts segments).  An image whose partners fill k segments -- the rule on a block flown in strips --
+        // no longer holds the turn for k segments while three waves wait with one product set each: four waves form products side by side
+        // in every pass, as on a scene with one segment per image.  Images without a partner in this chunk (most of them, with locality)
+        // are never visited: every wave reads the ranges of up to 64 images of the point with ONE vector load and finds its segments by
+        // scalar bit scans of a ballot.
+        PPData<FUSED> cur, nxt;
+        double apc[6], upc[12];
+        int turn_base = 0;
+        for (int wb = ob; wb < oe; wb += 64) {
+            int2 rl = make_int2(0, 0);
+            if (wb + lane < oe) rl = rng[(long)(wb + lane) * nrc + rci];
+            const int nseg_l = rl.y > rl.x ? (rl.y - rl.x + 63) >> 6 : 0;
+            // scalar walk over (pass s, images with a segment s): state of the generator
+            int gs = 0, gidx = 0;                        // pass, rank of the NEXT candidate among the images of this pass
+            unsigned long long gm = __ballot(nseg_l > 0);
+            int gbase = turn_base;                       // turn position of rank 0 of this pass
+            // item = (lane b of its image in the window, pass s, turn position); b < 0: none left
+            auto next_item = [&](int &b, int &sg, int &pos) __attribute__((always_inline)) {
+                for (;;) {
+                    if (gm == 0ull) {                    // next pass
+                        gbase += gidx;
+                        ++gs; gidx = 0;
+                        gm = __ballot(nseg_l > gs);
+                        if (gm == 0ull) { b = -1; return; }
+                    }
+                    const int bit = __builtin_ctzll(gm);
+                    gm &= gm - 1ull;
+                    const int k = gidx++;
+                    if ((k & (NW - 1)) == wave) { b = bit; sg = gs; pos = gbase + k; return; }
+                }
+            };
+            static_assert((NW & (NW - 1)) == 0, "waves per workgroup: a power of two");
+            int b0, s0, p0, b1, s1, p1;
+            next_item(b0, s0, p0);
+            if (b0 >= 0) {
+                next_item(b1, s1, p1);
+                PPRecord r0 = pp_record(pp.recs, wb + b0);
+                PPRecord r1 = pp_record(pp.recs, wb + (b1 >= 0 ? b1 : b0));
+                {
+                    const int gx = __builtin_amdgcn_readlane(rl.x, b0), gy = __builtin_amdgcn_readlane(rl.y, b0);
+                    pp_load<FUSED, MIXED>(cur, p, r0, pp.ipcol, rowsA, Ubuf, gx + 64 * s0 + lane, gy, pp.ug);
+                    pp_spread_row<FUSED>(pp_fetch_row<FUSED>(p, r0, rowsA, Ubuf, lane), sigma2, apc, upc);
+                }
+                for (;;) {
+                    int b2, s2, p2;
+                    if (b1 >= 0) next_item(b2, s2, p2); else b2 = -1;
+                    const PPRecord r2 = pp_record(pp.recs, wb + (b2 >= 0 ? b2 : (b1 >= 0 ? b1 : b0)));      // two items ahead, like the image-major loop
+                    double rown = 0.0;
+                    if (b1 >= 0) {
+                        const int gx = __builtin_amdgcn_readlane(rl.x, b1), gy = __builtin_amdgcn_readlane(rl.y, b1);
+                        pp_load<FUSED, MIXED>(nxt, p, r1, pp.ipcol, rowsA, Ubuf, gx + 64 * s1 + lane, gy, pp.ug);
+                        rown = pp_fetch_row<FUSED>(p, r1, rowsA, Ubuf, lane);
+                    }
+                    if constexpr (DET) {
+                        double gq[6];
+                        const int cqs[3] = {cur.cq[0], cur.cq[1], cur.cq[2]};
+                        pp_products<FUSED>(cur, upc, sigma2, gq);
+                        int spin = 0;
+                        while (__hip_atomic_load(det_turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != p0) {
+                            __builtin_amdgcn_s_sleep(0);
+                            if (++spin > (1 << 26)) { gq[0] = __builtin_nan(""); break; }      // (bounded: see the image-major loop)
+                        }
+                        asm volatile("" ::: "memory");
+                        pp_apply(gq, cqs, apc, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) __hip_atomic_store(det_turn, p0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        pp_accumulate<FUSED>(cur, apc, upc, sigma2, strip, cw, c0, cp0, cp1, cp2, wlo, whi);
+                    }
+                    if (b1 < 0) break;
+                    cur = nxt;
+                    pp_spread_row<FUSED>(rown, sigma2, apc, upc);
+                    b0 = b1; s0 = s1; p0 = p1; r0 = r1;
+                    b1 = b2; s1 = s2; p1 = p2; r1 = r2;
+                }
+            }
+            // every wave has walked the same lists: the turn positions of the next window start behind this one's segments
+            {
+                int total = 0;
+                for (int sg = 0;; sg++) {
+                    const unsigned long long m = __ballot(nseg_l > sg);
+                    if (m == 0ull) break;
+                    total += __builtin_popcountll(m);
+                }
+                turn_base += total;
+            }
+        }
+    } else
     if (ob + wave < oe) {
         int o = ob + wave;
         PPRecord r1 = pp_record(pp.recs, o);
@@ -1068,7 +1161,7 @@ hipError_t launch_assemble_blocks(hipStream_t s, const DevProblem &p, const int3
             const bool mixed = p.ip_w3 != nullptr;       // (a separate instance: the dense-only kernel keeps its code and its registers)
             if (det && mixed) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
             else if (mixed) hipLaunchKernelGGL((blk_pp_gather_kernel<true, false, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
-            else if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
+            else if (det) hipLaunchKernelGGL((blk_pp_gather_kernel<true, true, false, true>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);      // pass-major (round 5)
             else hipLaunchKernelGGL((blk_pp_gather_kernel<true, false>), gg, gb, lds, s, p, pp, rowsA, sb.U, sigma2, N);
         } else {
             const bool mixed = q.ip_w3 != nullptr;
