@@ -260,7 +260,7 @@ def main():
                            "note": "iterative refinement of dx (two-fold-precision residual + forward/backward substitution), inside the timed step (stage 'solve')"},
             "roofline": {"kernel": ("gemm_f64_kernel<0, 0, 128, 128, 1> (Cholesky trailing update of the stream-scheduled factorisation, fp64 MFMA 16x16x4)"
                                     if os.environ.get("JAICOV_FACTOR_FORM") == "streams" else
-                                    "chol_tile_kernel<1, false> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
+                                    "chol_tile_kernel<2, false> (dataflow Cholesky: the whole factorisation of the EO-reduced normal matrix in one "
                                     "persistent launch, fp64 MFMA 16x16x4, with potrf_chain_kernel's two workgroups beside it for the diagonal "
                                     "blocks; algorithmic flops = order^3 / 3; symbols as listed by rocprofv3)"),
                          "bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -304,7 +304,7 @@ def main():
             kr = json.load(open(os.path.join(ROOT, "bundle-adjustment_amd", "csrc", "kernel_resources.json")))
             # (blk_pp_gather_kernel<true, true, false, true>: the deterministic assembly (the default; pass-major since round 5), <true, false, false, false> the arrival-order form; chol_tile_kernel<1, true>: the one-kernel form the PMC counters
             # are collected on -- not kernels of the default LM pass, listed because figures of this line's family quote them)
-            lm = ("chol_tile_kernel<1, false>", "chol_tile_kernel<1, true>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false, false", "blk_pp_gather_kernel<true, true, false", "blk_T_mfma_kernel", "blk_elim_kernel",
+            lm = ("chol_tile_kernel<2, false>", "chol_tile_kernel<1, true>", "potrf_chain_kernel", "blk_pp_gather_kernel<true, false, false", "blk_pp_gather_kernel<true, true, false", "blk_T_mfma_kernel", "blk_elim_kernel",
                   "blk_tfix_kernel", "blk_cc", "blk_pc_gather", "rows_kernel", "backsolve_chain8_kernel", "forwardsolve_chain8_kernel", "forwardsolve_chain_kernel", "gemm_f64_kernel<0, 1, 128, 128, 0>",
                   "symv_dd_tile_kernel", "symv_dd_reduce_kernel", "blk_backsub_kernel", "damp_and_precond_kernel")
             tab = {}

@@ -1313,7 +1313,6 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
     flow_wg_off = (int)(g.wgstate - g.ctrl);
     HIPCHK(hipMemcpyAsync(flow_flags + FLOW_WG_OFF, &flow_wg_off, sizeof(int), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemsetAsync(d_info, 0, sizeof(int), stream));
-    // (operand loads TWO k-steps ahead, chol_tile_kernel<2, false>: measured equal, 22.7-23.0 ms at order 15 104 -- one step of lead covers the latency)
     if (flow_one_kernel) {
         // Kernels cannot run side by side here (every dispatch serialised: counter collection, a debugging environment): the
         // diagonal kernel and the tile kernel would wait for each other until the time limit.  ONE kernel, diagonal blocks inline.
@@ -1365,7 +1364,10 @@ hipError_t DenseSolver::potrf_flow(hipEvent_t all_ready) {
         }
     }
     if (profile) HIPCHK(hipEventRecord(flow_t0, stream));
-    hipLaunchKernelGGL((chol_tile_kernel<1, false>), dim3(flow_grid), dim3(256), 0, stream, g);
+    // operand loads TWO k-steps ahead (chol_tile_kernel<2, false>, 256 VGPRs, no scratch).  Measured equal to one step of lead in round 2, when
+    // the backlog of the late columns hid everything; with the split update ranges the latency of the short runs at the dependency front shows:
+    // 21.6 -> 21.35 ms at 118 block columns, 5.30 -> 5.19 at 64, equal at 24 (round 5)
+    hipLaunchKernelGGL((chol_tile_kernel<2, false>), dim3(flow_grid), dim3(256), 0, stream, g);
     if (profile) {
         HIPCHK(hipEventRecord(flow_t1, stream));
         flow_timed = true;
