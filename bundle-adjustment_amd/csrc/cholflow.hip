@@ -1176,7 +1176,9 @@ static FlowResidency flow_measure_residency(hipStream_t stream, hipStream_t dstr
         fprintf(stderr, "jaicov: residency of the tile kernel beside %d chain workgroups (grid %d): %s; %d XCDs, %d shader engines each, %d blocks dealt per XCD, "
                 "at least %d resident at once (%d on the fullest-booked shader engine), at most %d queued -> blocks >= %d of a chain workgroup's XCD leave without a ticket\n",
                 chain_wgs, grid, r.valid ? "measured" : "NOT measured", r.n_xcd, r.n_se, r.dealt, r.resident_min, r.se_cap, r.queued_max, r.keep);
-    cache.push_back({{grid, chain_wgs}, r});
+    // (a measurement taken while another engine of the process was computing can come out short of residents: it is used -- a smaller
+    // `keep` costs a few workers, never correctness -- but not remembered, so that the next solver measures again)
+    if (r.valid && r.queued_max <= 3 * std::max(1, r.n_se)) cache.push_back({{grid, chain_wgs}, r});
     return r;
 }
 extern "C" int jaicov_debug_flow_residency(int *out8) {       // tests / DESIGN.md: {valid, XCDs, shader engines, dealt, resident min, queued max, keep, 0}
