@@ -46,6 +46,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1129,6 +1130,8 @@ __global__ __launch_bounds__(256, 2) void flow_residency_probe_kernel(int *count
 
 static FlowResidency flow_measure_residency(hipStream_t stream, hipStream_t dstream, int grid, int chain_wgs) {
     static std::vector<std::pair<std::pair<int, int>, FlowResidency>> cache;
+    static std::mutex cache_mutex;                      // engines may be created from several host threads
+    std::lock_guard<std::mutex> lock(cache_mutex);      // (held across the measurement: two probes at once would measure each other)
     for (auto &c : cache)
         if (c.first == std::make_pair(grid, chain_wgs)) return c.second;
     FlowResidency r;
