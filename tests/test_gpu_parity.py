@@ -146,6 +146,51 @@ def test_factor_tile_by_tile_at_the_orders_between(n):
     np.testing.assert_allclose(np.tril(out), np.linalg.cholesky(S), rtol=0, atol=1e-11)
 
 
+def test_gather_with_partner_ranges_longer_than_a_wave():
+    """A block flown in strips (scene layout "strips": neighbouring points are neighbouring columns) with dense per-image dispersions and 150
+    points per image: an image's partners of a row point fill SEVERAL 64-lane segments of one strip, and most (image, strip) pairs are empty.
+    That is the regime the deterministic gather's pass-major distribution was built for (round 5: segments dealt to the waves pass by pass,
+    the turn word counts segments, images without a partner in the strip are never visited) and the small random scenes never reach (at
+    most 60 points per image).  The oracle's literal stacking needs minutes at this size, so the deterministic (pass-major) engine is held
+    to the arrival-order engine -- the image-major loop, which the other tests of this file hold to the oracle: the reduced N and n to summation-
+    order rounding, the step and Omega; and to itself: the same bits on a rebuild."""
+    fp = scene.make_scene(40, 600, 150, layout="strips", dist=scene.DIST_FULL, weights="block", n_control=8, control_dense=True)
+    s2, U = fp.sigma2apriori, fp.n_unknowns
+    pc = fp.point_col.reshape(-1, 3)[:, 0]
+    longest = 0
+    for img in range(fp.n_images):
+        cols = pc[fp.ip_point[fp.ip_image == img]]
+        longest = max(longest, int(np.bincount(cols[cols >= 0] // 256).max()))
+    assert longest > 64                                  # more partners of one image in 256 columns than a wave has lanes
+    out = {}
+    for det in (True, False):
+        eng = engine.Engine(fp, deterministic=det)
+        eng.set_parameters(fp.values)
+        eng.build(s2, 0.0)
+        e0 = eng.reduced_order()
+        assert e0 == U - 6 * fp.n_images               # the fused (EO-eliminating) gather ran
+        N1, n1 = eng.get_normal()
+        dx = eng.solve(False)
+        om = eng.omega(s2, dx)
+        eng.build(s2, 0.0)
+        N2, n2 = eng.get_normal()
+        if det:
+            assert np.array_equal(N1, N2) and np.array_equal(n1, n2)
+        out[det] = (N1[:e0 * (e0 + 1) // 2], n1[:e0], dx, om)
+        eng.close()
+    Nd, nd, dxd, omd = out[True]
+    Na, na, dxa, oma = out[False]
+    idx = np.arange(nd.size, dtype=np.int64)
+    dg = np.sqrt(np.abs(Na[idx * (idx + 3) // 2])); dg[dg == 0] = 1.0
+    r = np.repeat(idx, idx + 1)                          # row of every packed entry (row-major lower = packed 'U')
+    c = np.concatenate([np.arange(k + 1) for k in range(nd.size)]) if nd.size < 4000 else None
+    assert c is not None
+    assert (np.abs(Nd - Na) / (dg[r] * dg[c])).max() < 1e-12
+    np.testing.assert_allclose(nd, na, rtol=0, atol=1e-12 * np.abs(na).max())
+    np.testing.assert_allclose(dxd, dxa, rtol=0, atol=1e-9 * np.abs(dxa).max())
+    assert abs(omd - oma) <= 1e-10 * oma
+
+
 def test_keep_rule_is_derived_from_measured_residency():
     """Round 5: which of the tile kernel's last workgroups take no ticket is no longer "the last eight of every XCD of an
     8 x 32 x 2 grid" but follows from a residency measurement beside stand-ins of the chain workgroups (cholflow.hip,
