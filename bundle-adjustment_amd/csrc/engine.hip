@@ -1585,6 +1585,30 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
         std::vector<double> xE((size_t)6 * e->p.n_images);
         HIPE(e, hipMemcpyAsync(xE.data(), e->d_xE, xE.size() * sizeof(double), hipMemcpyDeviceToHost, e->stream));
         HIPE(e, hipStreamSynchronize(e->stream));
+        {
+            // Round 5: once in ~10 runs of the GPU test-suite a solve returned an EO step of EXACT zeros for every image (N, n and the reduced
+            // step correct; 1 200 solves of the same scene alone: never).  The back-substitution kernel cannot produce that from finite
+            // operands, so the copy is checked: all zeros -> read again with a blocking copy after a device-wide wait, and say so.
+            bool all_zero = !e->h_blk_images.empty();
+            for (int img : e->h_blk_images)
+                for (int k = 0; k < 6 && all_zero; k++) all_zero = xE[(size_t)6 * img + k] == 0.0;
+            if (all_zero) {
+                HIPE(e, hipDeviceSynchronize());
+                HIPE(e, hipMemcpy(xE.data(), e->d_xE, xE.size() * sizeof(double), hipMemcpyDeviceToHost));
+                bool still = true;
+                for (int img : e->h_blk_images)
+                    for (int k = 0; k < 6 && still; k++) still = xE[(size_t)6 * img + k] == 0.0;
+                if (still) {      // the kernel itself left zeros: run the two kernels once more
+                    HIPE(e, launch_omega(e->stream, e->p, e->d_in_block, e->ip0, e->ip_count, e->d_blk_list, 0, e->max_m, e->d_rowsA,
+                                         e->d_rowsW, e->d_dx, 1.0, e->d_vbuf, e->d_omega));
+                    HIPE(e, launch_schur_backsub(e->stream, e->p, e->d_blk_list, e->n_blk_list, e->sb.U, e->sb.Linv, e->d_vbuf, e->d_xE));
+                    HIPE(e, hipStreamSynchronize(e->stream));
+                    HIPE(e, hipMemcpy(xE.data(), e->d_xE, xE.size() * sizeof(double), hipMemcpyDeviceToHost));
+                }
+                fprintf(stderr, "jaicov: the exterior-orientation step came back as exact zeros; %s\n",
+                        still ? "the back-substitution was run again" : "a second, blocking copy had the values (the first copy returned before the data)");
+            }
+        }
         for (int img : e->h_blk_images)
             for (int k = 0; k < 6; k++) {
                 dx_out[e->e0 + 6 * img + k] = xE[(size_t)6 * img + k];
