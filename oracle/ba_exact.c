@@ -155,6 +155,39 @@ double oracle_inverse_residual_q(int m, const double *D, const double *X_hi, con
     return worst;
 }
 
+/* The same certificate over the WHOLE matrix at the price of a few matrix-vector products: for nvec vectors v of random signs,
+ * max_i |(v - D (X v) / scale)_i| with X = X_hi + X_lo, everything in binary128 (2 m^2 software multiplications per vector instead of
+ * m^3).  With R = I - D X / scale this is max_i |sum_j R_ij v_j|: a row of R whose 2-norm is rho shows up as ~rho in every probe, so a
+ * handful of probes bounds every row of the residual (not its single largest entry, which the row-wise check above measures exactly).
+ * The signs come from a 64-bit LCG seeded by the caller: the same numbers in every run. */
+double oracle_inverse_residual_probe_q(int m, const double *D, const double *X_hi, const double *X_lo, double scale, int nvec,
+                                       unsigned long long seed) {
+    double worst = 0;
+    __float128 *v = (__float128 *)malloc(sizeof(__float128) * (size_t)m), *y = (__float128 *)malloc(sizeof(__float128) * (size_t)m);
+    unsigned long long st = seed * 6364136223846793005ULL + 1442695040888963407ULL;
+    for (int t = 0; t < nvec; t++) {
+        for (int j = 0; j < m; j++) {
+            st = st * 6364136223846793005ULL + 1442695040888963407ULL;
+            v[j] = (st >> 62) & 1 ? 1 : -1;
+        }
+        for (int i = 0; i < m; i++) {
+            const double *xh = X_hi + (size_t)i * m, *xl = X_lo ? X_lo + (size_t)i * m : NULL;
+            __float128 s = 0;
+            for (int j = 0; j < m; j++) s += ((__float128)xh[j] + (xl ? (__float128)xl[j] : 0)) * v[j];
+            y[i] = s;
+        }
+        for (int i = 0; i < m; i++) {
+            const double *di = D + (size_t)i * m;
+            __float128 s = (__float128)scale * v[i];
+            for (int j = 0; j < m; j++) s -= (__float128)di[j] * y[j];
+            double a = fabs((double)(s / (__float128)scale));
+            if (a > worst) worst = a;
+        }
+    }
+    free(v); free(y);
+    return worst;
+}
+
 /* P = sigma2 * inv(D) of image block blk as a (hi, lo) pair of row-major m x m fp64 matrices */
 int oracle_exact_block_weight(const jaicov_problem_desc *d, double sigma2, int blk, double *P_hi, double *P_lo) {
     int m = 2 * (d->blk_ip_begin[blk + 1] - d->blk_ip_begin[blk]);

@@ -80,6 +80,8 @@ def lib():
         L.oracle_exact_block_weight.argtypes = [P, C.c_double, C.c_int, _pd, _pd]
         L.oracle_inverse_residual_q.argtypes = [C.c_int, _pd, _pd, _pd, C.c_double, C.c_int, C.c_int]
         L.oracle_inverse_residual_q.restype = C.c_double
+        L.oracle_inverse_residual_probe_q.argtypes = [C.c_int, _pd, _pd, _pd, C.c_double, C.c_int, C.c_ulonglong]
+        L.oracle_inverse_residual_probe_q.restype = C.c_double
         L.oracle_residual_ld2.argtypes = [C.c_int, _pd, _pd, C.c_int, _pd, _pd, _pd, _pd]
         L.oracle_residual_ld2.restype = None
         L.oracle_matvec_ld2.argtypes = [C.c_int, _pd, _pd, _pd, _pd]

@@ -305,6 +305,36 @@ def test_extended_precision_weight_is_certified_in_binary128(oracle_mod):
     assert 1e-16 < err < 1e-9, err
 
 
+def test_every_weight_matrix_is_certified_by_binary128_probes(oracle_mod):
+    """The row-wise certificate above costs m^3 software multiplications and therefore looks at 64 rows of one matrix.  The probe form
+    (oracle_inverse_residual_probe_q: |v - D P v / sigma0^2| for random sign vectors, binary128) covers every row for 2 m^2 per vector:
+    here every block of a scene, and in the committed tests/golden/cfg4/cfg4_weight_certificate.json (make_weight_certificate.py) all
+    500 weight matrices of config 4 -- the ones the truth fixture cfg4_exactN.npz is assembled from."""
+    import json
+    import os
+    L = oracle_mod.lib()
+    pd = oracle_mod._p
+    fp = scene.make_scene(3, 300, 300, dist=scene.DIST_RADIAL, weights="block", n_control=4)
+    o = oracle_mod.Oracle(fp)
+    s2 = fp.sigma2apriori
+    for b in range(fp.n_image_blocks):
+        Ph, Pl = o.exact_block_weight(s2, b)
+        P64 = o.block_weight(s2, b)
+        m = Ph.shape[0]
+        D = np.ascontiguousarray(fp.blk_disp[fp.blk_disp_offset[b]:fp.blk_disp_offset[b] + m * m])
+        r_exact = L.oracle_inverse_residual_probe_q(m, pd(D), pd(Ph), pd(Pl), s2, 2, b + 1)
+        r_fp64 = L.oracle_inverse_residual_probe_q(m, pd(D), pd(P64), None, s2, 2, b + 1)
+        assert r_exact < 2e-15 and r_exact < 1e-3 * r_fp64, (b, r_exact, r_fp64)
+        # the probe sees what the exact row-wise residual sees (a row's 2-norm against its largest entry: within m^(1/2))
+        rows = L.oracle_inverse_residual_q(m, pd(D), pd(Ph), pd(Pl), s2, 0, 8)
+        assert rows <= r_exact * 4 and r_exact <= rows * 4 * m ** 0.5, (rows, r_exact)
+    meta = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg4", "cfg4_weight_certificate.json")))
+    assert meta["blocks"] == 500 and len(meta["per_block_residual_exact"]) == 500 and meta["order_min"] == meta["order_max"] == 1000
+    assert meta["residual_exact_max"] < 1e-13                                   # every one of the 500 is an inverse to binary128's witness
+    assert meta["residual_fp64_min"] > 1000 * meta["residual_exact_max"]         # ... and every fp64 dpptri weight is visibly not
+    assert 1e-12 < meta["fp64_weight_error_median"] < 1e-9                      # cond(D) eps: what separates the oracle's N from the exact one
+
+
 @pytest.mark.parametrize("name", ["tiny", "tiny_block", "tiny_free"])
 def test_extended_precision_assembly_agrees_with_the_restatement(oracle_mod, name):
     """oracle_exact_accumulate (every group kind: ordinary 2 x 2 / diagonal image points, dense image blocks, scale bar, dense and
