@@ -82,3 +82,44 @@ def test_two_ranks_on_one_gpu_match_the_oracle(tmp_path, oracle_mod):
     dxo2, Qo2, _, _ = o.step(vals, fp.sigma2apriori, 0.0, True)
     np.testing.assert_allclose(r0[base:base + U], dxo2, rtol=0, atol=1e-9 * max(np.abs(dxo2).max(), np.abs(dxo).max()))
     np.testing.assert_allclose(r0[base + U:base + U + nq], Qo2, rtol=0, atol=1e-9 * np.abs(Qo2).max())
+
+
+def test_shards_without_the_exchange_promise_take_the_literal_full_route(oracle_mod):
+    """a sharded engine whose caller has NOT promised to sum the expansion's inputs (engine option expansion_exchange
+    off) cannot expand the reduced inverse -- it holds its own images' F bands and L_E^-1 only --, so a final pass announced as
+    FULL_EXPANDED falls back to the literal FULL route (engine.hip effective_invert): the UNREDUCED system is assembled per shard,
+    summed (here: two engines in one process, the buffers added with torch as the all-reduce would), factored and inverted at full order.
+    Held to the oracle's dspsv + dsptri (MX:338-366)."""
+    import torch
+    from bundle_adjustment_amd import distributed, engine
+    from bundle_adjustment_amd.distributed import DeviceArray
+    fp = _scene()
+    s2, U = fp.sigma2apriori, fp.n_unknowns
+    dev = torch.device("cuda", 0)
+    parts = distributed.partition_images(fp, 2)
+    engs = [engine.Engine(fp, image_range=parts[r], apply_shared=(r == 0)) for r in range(2)]
+    for e in engs:
+        e.set_parameters(fp.values)
+        e.prepare_inverse(engine.INVERT_FULL_EXPANDED)
+        e.accumulate(s2, 0.0)
+    assert all(e.reduced_order() == U for e in engs)                        # nothing was pre-eliminated: the literal route
+    ts = [torch.as_tensor(DeviceArray(*e.reduce_buffer()), device=dev) for e in engs]
+    assert ts[0].numel() == ts[1].numel() == U * (U + 1) // 2 + U
+    tot = ts[0] + ts[1]
+    for t in ts:
+        t.copy_(tot)
+    torch.cuda.synchronize(dev)
+    out = []
+    for e in engs:
+        e.finalize(s2, 0.0)
+        dx = e.solve(engine.INVERT_FULL_EXPANDED)
+        assert e.cofactor_order() == U
+        out.append((dx, e.get_cofactor()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    o = oracle_mod.Oracle(fp)
+    dxo, Qo, _, _ = o.step(fp.values, s2, 0.0, True)
+    np.testing.assert_allclose(out[0][0], dxo, rtol=0, atol=1e-9 * np.abs(dxo).max())
+    np.testing.assert_allclose(out[0][1], Qo, rtol=0, atol=1e-9 * np.abs(Qo).max())
+    for e in engs:
+        e.close()
