@@ -263,6 +263,42 @@ def test_a_large_ordinary_problem_is_eliminated_with_compact_weights():
     full.close()
 
 
+@pytest.mark.parametrize("per_image, eliminated", [(2048, True), (2049, False)])
+def test_the_largest_ordinary_image_that_is_served_as_a_block(per_image, eliminated):
+    """The limit of the elimination for ordinary images: 2 048 observations per image (4 096 rows: the elimination kernels' per-image panel).
+    At the limit the exterior orientations are eliminated; one observation more and the WHOLE problem keeps the full-order path
+    (all-or-nothing, engine.hip).  Either way the step is the full-order engine's."""
+    import dataclasses
+    fp = scene.make_scene(4, 2300, 2200, dist=scene.DIST_RADIAL, weights="2x2", n_control=6)
+    assert np.bincount(fp.ip_image).min() > per_image
+    seen = np.bincount(fp.ip_point)
+    keep = []
+    for i in range(4):                                             # exactly per_image observations per image: drop those of the most-seen points
+        idx = np.flatnonzero(fp.ip_image == i)
+        drop = idx[np.argsort(-seen[fp.ip_point[idx]], kind="stable")[:idx.size - per_image]]
+        seen[fp.ip_point[drop]] -= 1
+        keep.append(np.setdiff1d(idx, drop))
+    keep = np.concatenate(keep)
+    fp = dataclasses.replace(fp, n_observations=0, **{k: getattr(fp, k)[keep].copy() for k in
+                                                      ("ip_image", "ip_point", "ip_x", "ip_y", "ip_var_x", "ip_var_y", "ip_rho")}).validate()
+    U, s2 = fp.n_unknowns, fp.sigma2apriori
+    assert np.bincount(fp.ip_image).tolist() == [per_image] * 4 and np.bincount(fp.ip_point).min() >= 2
+    eng = engine.Engine(fp, ordinary_group_elimination=FORCE)
+    eng.set_parameters(fp.values)
+    eng.build(s2, 0.0)
+    assert eng.reduced_order() == (U - 6 * fp.n_images if eliminated else U)
+    dx = eng.solve(False)
+    om = eng.omega(s2, dx)
+    eng.close()
+    full = engine.Engine(fp, ordinary_group_elimination=-1)
+    full.set_parameters(fp.values)
+    full.build(s2, 0.0)
+    dxf = full.solve(False)
+    assert np.abs(dx - dxf).max() <= 1e-9 * np.abs(dxf).max()
+    assert abs(om - full.omega(s2, dxf)) <= 1e-9 * om
+    full.close()
+
+
 def test_default_eliminates_ordinary_images_only_where_it_saves_block_columns():
     """Round 5's size rule (engine.hip, create): the default serves ordinary images as blocks when the 6 I exterior-orientation columns are
     at least two 128-column blocks of the factorisation.  BASELINE config 2 (order 726 -> 606: six block columns -> five) stays at full
