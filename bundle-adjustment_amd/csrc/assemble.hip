@@ -561,7 +561,7 @@ __device__ __forceinline__ void pp_load(PPData<FUSED> &d, const DevProblem &p, c
         }
 #pragma unroll
         for (int b = 0; b < 3; b++) {
-            d.cq[b] = ipcol[3 * (long)(r.ipb + q) + b];
+            d.cq[b] = ipcol[(long)b * S + r.ipb + q];          // SoA like the other partner operands (round 5: as [ip][3] a wave's load touched 6 lines instead of 2)
             d.aq[2 * b] = rowsA[(long)(2 * b) * S + r.ipb + q];
             d.aq[2 * b + 1] = rowsA[(long)(2 * b + 1) * S + r.ipb + q];
         }

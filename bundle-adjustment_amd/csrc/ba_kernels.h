@@ -56,7 +56,7 @@ constexpr int PP_NT = JAICOV_PP_NT;   // threads per workgroup of the gather
 struct PPGather {
     const int32_t *pt_ip_begin = nullptr;   // [n_points+1] CSR over recs
     const PPRecord *recs = nullptr;         // image order within a point
-    const int32_t *ipcol = nullptr;         // [3*n_ip] column of X,Y,Z of the point seen by image point ip
+    const int32_t *ipcol = nullptr;         // [3][n_ip] column of X / Y / Z of the point seen by image point ip
     // the engine stores the points of a dense block in column order, so the partners that fall into column chunk c of
     // record o are the block positions range[2*(o*n_chunks+c)] .. range[..+1] (already cut at the row's own column:
     // only the lower triangle is assembled)

@@ -860,7 +860,13 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             }
             if ((rc = upload(e, cnt.data(), cnt.size(), &e->pp.pt_ip_begin))) return rc;
             if ((rc = upload(e, recs.data(), recs.size(), &e->pp.recs))) return rc;
-            if ((rc = upload(e, ipcol.data(), ipcol.size(), &e->pp.ipcol))) return rc;
+            {   // the gather reads the columns as three arrays over the image points (coalesced like A_q and U_q)
+                std::vector<int32_t> soa(ipcol.size());
+                const size_t S = (size_t)D->n_image_points;
+                for (size_t ip = 0; ip < S; ip++)
+                    for (int a = 0; a < 3; a++) soa[(size_t)a * S + ip] = ipcol[3 * ip + a];
+                if ((rc = upload(e, soa.data(), soa.size(), &e->pp.ipcol))) return rc;
+            }
             if ((rc = upload(e, range.data(), range.size(), &e->pp.range))) return rc;
             e->pp.det = e->deterministic ? 1 : 0;
             e->pp.cmin = cmin;
