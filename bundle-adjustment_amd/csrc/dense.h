@@ -23,8 +23,12 @@ int factor_form();                 // JAICOV_FACTOR_FORM (dense.hip): test hook 
 // Streams are kept for the life of the process (dense.hip): creating one costs 12-35 ms on this stack (a hardware queue is set up), destroying
 // one 5 ms, and an engine needs eight -- 100 ms of the 225 ms an engine creation took at BASELINE config 4.  stream_acquire hands out a
 // stream nobody else holds (a cached one if there is one of that kind for the current device, else a new one; nullptr if it cannot
-// be created); stream_release synchronises it and puts it back.
+// be created); stream_release synchronises it and puts it back.  CU-masked streams are the exception to "kept": each is a hardware queue
+// of its own, idle or not, and a process that holds more than ~16 has ALL its queues time-sliced (round 5: 94 block columns 19.5 ms with 8
+// idle ones beside the solver's, 28.8 with 16, 58 with 32; scripts/queue_count_probe.py) -- at most STREAM_MASKED_IDLE_MAX of a kind stay
+// in the pool, the rest are destroyed on release.
 enum { STREAM_PLAIN = 0, STREAM_HIGH_PRIORITY = 1, STREAM_UPDATE_CUS = 2, STREAM_DIAGONAL_CUS = 3, STREAM_KINDS = 4 };
+constexpr int STREAM_MASKED_IDLE_MAX = 2;
 hipStream_t stream_acquire(int kind);
 void stream_release(int kind, hipStream_t s);
 
@@ -61,6 +65,8 @@ struct DenseSolver {
     double *Q = nullptr;       // n x ld : (L L')^-1 (lower tiles valid; symmetrize() fills the rest); workspace of trtri()
     int *d_info = nullptr;     // first failing pivot (1-based), 0 = ok
     bool owns = false;
+    bool borrowed_streams = false;   // pstream (and what it holds of ustream / dstream) belong to another solver (init's `share`)
+    bool own_ustream = false, own_dstream = false;   // ... the masked streams this solver acquired itself
     // optional per-launch profiling of the trailing update (HIP events on `stream`)
     bool profile = false;
     std::vector<hipEvent_t> prof_ev;     // pairs
@@ -105,7 +111,10 @@ struct DenseSolver {
     hipError_t flow_enable_trace(bool on);
     void flow_report_stall();            // one line on stderr: how far the abandoned factorisation got
 
-    hipError_t init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows = false);
+    // `share`: a solver of the same engine that is never at work at the same time (the full-order and the EO-reduced solver of an engine):
+    // its side streams are used instead of streams of this solver's own -- a CU-masked stream is a HARDWARE QUEUE, and beyond ~16 of them
+    // in a process the scheduler time-slices the queues, persistent kernels included ("Hardware queues")
+    hipError_t init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows = false, const DenseSolver *share = nullptr);
     double *rhs_row(int q) const { return L + (long)(nfact + q) * ld; }   // row q of the right-hand sides / of Z = Y L^-T
     void release();
     hipError_t panel(hipStream_t st, int K0, int K1);

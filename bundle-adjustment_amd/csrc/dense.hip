@@ -835,6 +835,7 @@ std::map<std::pair<int, int>, std::vector<hipStream_t>> g_stream_pool;      // (
 // a profiler's finalisation: under rocprofv3 a process that left streams to the runtime's own teardown ended in a segmentation fault
 // inside __cxa_finalize, after the tool had written its output).
 std::vector<hipStream_t> g_all_streams;       // every stream stream_acquire has created and nobody has destroyed: idle ones and those of live (or leaked) engines
+std::map<hipStream_t, int> g_stream_kind;      // ... its kind (census below)
 std::map<hipStream_t, int> g_stream_device;    // ... and the device each belongs to (a stream is filed under ITS device whatever the caller's current one is)
 struct StreamPoolCleanup {
     ~StreamPoolCleanup() {
@@ -842,6 +843,7 @@ struct StreamPoolCleanup {
         for (hipStream_t s : g_all_streams) (void)hipStreamDestroy(s);
         g_all_streams.clear();
         g_stream_device.clear();
+        g_stream_kind.clear();
         g_stream_pool.clear();
     }
 } g_stream_pool_cleanup;
@@ -883,6 +885,7 @@ hipStream_t stream_acquire(int kind) {
     std::lock_guard<std::mutex> lock(g_stream_mutex);
     g_all_streams.push_back(s);
     g_stream_device[s] = dev;
+    g_stream_kind[s] = kind;
     return s;
 }
 
@@ -894,13 +897,37 @@ void stream_release(int kind, hipStream_t s) {
             std::lock_guard<std::mutex> lock(g_stream_mutex);
             g_all_streams.erase(std::remove(g_all_streams.begin(), g_all_streams.end(), s), g_all_streams.end());
             g_stream_device.erase(s);
+            g_stream_kind.erase(s);
         }
         hipStreamDestroy(s);
         return;
     }
+    {
+        std::lock_guard<std::mutex> lock(g_stream_mutex);
+        const auto it = g_stream_device.find(s);
+        std::vector<hipStream_t> &idle = g_stream_pool[{it == g_stream_device.end() ? 0 : it->second, kind}];
+        const bool masked = kind == STREAM_UPDATE_CUS || kind == STREAM_DIAGONAL_CUS;
+        if (!masked || (int)idle.size() < STREAM_MASKED_IDLE_MAX) {
+            idle.push_back(s);
+            return;
+        }
+        // a CU-masked stream beyond the few that are kept: its hardware queue goes back to the device (dense.h)
+        g_all_streams.erase(std::remove(g_all_streams.begin(), g_all_streams.end(), s), g_all_streams.end());
+        g_stream_device.erase(s);
+        g_stream_kind.erase(s);
+    }
+    (void)hipStreamDestroy(s);
+}
+
+// tests / DESIGN.md: streams of this library in the process, [kind] alive (held by solvers or idle) and [4 + kind] idle in the pool;
+// kinds: 0 plain, 1 high priority, 2 CU-masked (trailing updates), 3 CU-masked (diagonal blocks) -- the masked ones are hardware queues
+extern "C" void jaicov_debug_stream_census(int *out8) {
     std::lock_guard<std::mutex> lock(g_stream_mutex);
-    const auto it = g_stream_device.find(s);
-    g_stream_pool[{it == g_stream_device.end() ? 0 : it->second, kind}].push_back(s);
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (const auto &kv : g_stream_kind)
+        if (kv.second >= 0 && kv.second < 4) out8[kv.second]++;
+    for (const auto &kv : g_stream_pool)
+        if (kv.first.second >= 0 && kv.first.second < 4) out8[4 + kv.first.second] += (int)kv.second.size();
 }
 
 int factor_form() {
@@ -915,7 +942,7 @@ int factor_form() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows) {
+hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, bool with_rhs_rows, const DenseSolver *share) {
     stream = s;
     aug = with_rhs_rows;
     nfact = n_padded;
@@ -944,18 +971,31 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     // 2560 1.32 / 1.59, 3072 1.55 / 1.94 -> from 12 block columns on.
     const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 12;      // (the tests lower it)
     const bool flow_wanted = factor_form() != FACTOR_STREAMS && nfact / 128 >= flow_from;
-    {
+    borrowed_streams = share != nullptr && share->owns && !share->borrowed_streams && share->pstream != nullptr;
+    if (borrowed_streams) {
+        pstream = share->pstream;
+        // reserved CUs as below; what the other solver does not hold is acquired here and then is this solver's own to release
+        ustream = share->ustream;
+        dstream = share->dstream;
+        own_ustream = own_dstream = false;
+    } else {
         pstream = stream_acquire(STREAM_HIGH_PRIORITY);
         if (!pstream) return hipErrorUnknown;
-        // reserved CUs: CU 31 of every XCD for the diagonal blocks, the other 31 for the trailing updates (stream_acquire)
+        own_ustream = own_dstream = false;
+    }
+    {
+        // reserved CUs: CU 31 of every XCD for the diagonal blocks, the other 31 for the trailing updates (stream_acquire).  The masked
+        // stream of the trailing updates is only held by a solver that factorises by the stream-scheduled form: the dataflow form
+        // (flow_wanted) launches its tile kernel on the ordinary stream, and every CU-masked stream is a hardware queue (dense.h).
         if (nfact >= 2048 || flow_wanted) {
             reserved_cus = 8;
-            ustream = stream_acquire(STREAM_UPDATE_CUS);
-            dstream = stream_acquire(STREAM_DIAGONAL_CUS);
-            if (!ustream || !dstream) {
-                stream_release(STREAM_UPDATE_CUS, ustream);
-                stream_release(STREAM_DIAGONAL_CUS, dstream);
+            if (!dstream) { dstream = stream_acquire(STREAM_DIAGONAL_CUS); own_dstream = dstream != nullptr; }
+            if (!flow_wanted && !ustream) { ustream = stream_acquire(STREAM_UPDATE_CUS); own_ustream = ustream != nullptr; }
+            if (!dstream || (!flow_wanted && !ustream)) {
+                if (own_ustream) stream_release(STREAM_UPDATE_CUS, ustream);
+                if (own_dstream) stream_release(STREAM_DIAGONAL_CUS, dstream);
                 ustream = dstream = nullptr;
+                own_ustream = own_dstream = false;
             }
         }
     }
@@ -979,7 +1019,10 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     }
     if (flow_wanted && dstream) {
         hipError_t fe = flow_init();
-        if (fe != hipSuccess) { flow_release(); (void)hipGetLastError(); }   // the stream-scheduled factorisation remains
+        if (fe != hipSuccess) {      // the stream-scheduled factorisation remains: it wants the masked stream of the trailing updates after all
+            flow_release(); (void)hipGetLastError();
+            if (!ustream) { ustream = stream_acquire(STREAM_UPDATE_CUS); own_ustream = ustream != nullptr; }
+        }
     }
     return hipSuccess;
 }
@@ -997,10 +1040,11 @@ void DenseSolver::release() {
     prof_ev.clear();
     for (auto ev : sync_ev) hipEventDestroy(ev);
     sync_ev.clear();
-    stream_release(STREAM_HIGH_PRIORITY, pstream);
-    stream_release(STREAM_UPDATE_CUS, ustream);
-    stream_release(STREAM_DIAGONAL_CUS, dstream);
+    if (!borrowed_streams) stream_release(STREAM_HIGH_PRIORITY, pstream);
+    if (own_ustream) stream_release(STREAM_UPDATE_CUS, ustream);
+    if (own_dstream) stream_release(STREAM_DIAGONAL_CUS, dstream);
     pstream = ustream = dstream = nullptr;
+    borrowed_streams = own_ustream = own_dstream = false;
     L = invd = W = Q = nullptr;
     if (pm_e0) hipEventDestroy(pm_e0);
     if (pm_done) hipEventDestroy(pm_done);

@@ -1009,7 +1009,7 @@ static int create_impl(jaicov_engine *e, const jaicov_problem_desc *D_in, const 
             e->e0 = e0;
             // the solver of the reduced system is created here, with its streams, not at the first solve: stream creation
             // order matters when the host also runs RCCL (bench.py: communicator after the engine)
-            HIPE(e, e->solverS.init(e->stream, ((e0 + 127) / 128) * 128, false, true));
+            HIPE(e, e->solverS.init(e->stream, ((e0 + 127) / 128) * 128, false, true, &e->solver));      // never at work beside the full-order solver: shares its side streams
             e->solverS_ready = true;
         }
     }
@@ -1352,7 +1352,7 @@ extern "C" int jaicov_neq_solve(jaicov_engine *e, int invert, double *dx_out) {
     const int U = schur ? e->e0 : e->U, d = e->d, nrhs = d + 1;
     const int Upad = e->Upad;                      // leading dimension of N, V, B and the rhs/solution vectors
     if (schur && !e->solverS_ready) {
-        HIPE(e, e->solverS.init(e->stream, ((e->e0 + 127) / 128) * 128, false, true));
+        HIPE(e, e->solverS.init(e->stream, ((e->e0 + 127) / 128) * 128, false, true, &e->solver));
         e->solverS_ready = true;
     }
     DenseSolver &slv = schur ? e->solverS : e->solver;

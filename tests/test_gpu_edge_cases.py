@@ -157,3 +157,34 @@ def test_incomplete_distortion_model_is_rejected():
     with pytest.raises(engine.EngineError) as ei:
         engine.Engine(bad)
     assert ei.value.code == -1
+
+
+def test_an_engine_holds_one_cu_masked_hardware_queue_and_the_pool_keeps_two():
+    """A CU-masked stream is a hardware queue of its own, idle or not; with ~20 of them in a process the scheduler time-slices ALL queues and a
+    factorisation of 94 block columns takes 29 ms instead of 19 (32 of them: 58 ms; scripts/queue_count_probe.py) -- and the bounded waits of
+    the dataflow factorisation start to run out (round 5: the GPU suite's "rare stalls", DESIGN.md section 4 "Hardware queues").  Until then
+    every solver held two such streams, every engine has two solvers, and the pool kept them all for the life of the process.  Now: the
+    dataflow solver holds ONE (the chain workgroups'), the EO-reduced solver shares the full-order solver's, and the pool keeps at most two
+    idle ones of a kind."""
+    import ctypes as C
+    lib = engine.load_library()
+
+    def census():
+        a = (C.c_int * 8)()
+        lib.jaicov_debug_stream_census(a)
+        return list(a)
+
+    fp = scene.config("cfg3")              # 24 block columns after the elimination: the dataflow factorisation, full-order and reduced solver
+    before = census()
+    engs = [engine.Engine(fp) for _ in range(5)]
+    for e in engs:
+        e.set_parameters(fp.values)
+        e.build(fp.sigma2apriori, 0.0)
+        e.solve(False)
+    alive = census()
+    held = [alive[k] - alive[4 + k] for k in range(4)]                 # streams in the hands of the five engines, per kind
+    assert held[2] == 0 and held[3] == 5, (before, alive)              # no masked stream for trailing updates, one for the chain workgroups each
+    for e in engs:
+        e.close()
+    after = census()
+    assert after[2] <= 2 and after[3] <= 2 and after[6] == after[2] and after[7] == after[3], after    # all idle, and no more than two of a kind left
