@@ -1148,7 +1148,7 @@ static FlowResidency flow_measure_residency(hipStream_t stream, hipStream_t dstr
         ok = alive();
         if (ok) {
             hipLaunchKernelGGL(flow_residency_probe_kernel, dim3(grid), dim3(256), 0, stream, counts, host + 4);
-            std::this_thread::sleep_for(std::chrono::milliseconds(3));      // every workgroup that fits has started and counted itself
+            std::this_thread::sleep_for(std::chrono::milliseconds(12));     // every workgroup that fits has started and counted itself (3 ms were not always enough right after a big engine's allocations)
         }
         __atomic_store_n(host + 4, 1, __ATOMIC_RELEASE);
         ok = hipStreamSynchronize(stream) == hipSuccess && hipStreamSynchronize(dstream) == hipSuccess && ok &&
@@ -1163,15 +1163,20 @@ static FlowResidency flow_measure_residency(hipStream_t stream, hipStream_t dstr
         r.resident_min = full;
         for (int x = 0; x < 16; x++)
             if (h[16 + x] > 0) { r.resident_min = std::min(r.resident_min, h[x]); r.queued_max = std::max(r.queued_max, h[16 + x] - h[x]); }
-        // the rule: of the blocks dealt to an XCD that hosts a chain workgroup, the last  max(2 per shader engine, the queued ones + one per
-        // further shader engine)  leave at once -- on the MI355X 8 of 64 (5 queued, 4 shader engines), i.e. keep = 448 of 512, the value the
-        // soaks of rounds 3-5 ran with.  Nothing queued anywhere (another device shape, another footprint): no rule.
-        const int leave = r.queued_max > 0 ? std::max(2 * r.n_se, r.queued_max + r.n_se - 1) : 0;
-        r.keep = leave > 0 && r.n_xcd > 0 && grid % r.n_xcd == 0 && r.dealt > leave ? r.n_xcd * (r.dealt - leave) : 0;
+        // the rule: of the blocks dealt to an XCD that hosts a chain workgroup, the last  dealt - shader engines x (capacity of the engine
+        // whose CU is taken)  leave at once -- on the MI355X 64 - 4 x 14 = 8, i.e. keep = 448 of 512, the value the soaks of rounds 3-5 ran
+        // with.  Nothing queued anywhere (another device shape, another footprint): no rule.
         r.se_cap = 1 << 30;      // fewest workgroups resident at once on one shader engine (the one whose CU a chain workgroup holds)
         for (int x = 0; x < 16; x++)
             for (int q = 0; q < r.n_se; q++)
                 if (h[16 + x] > 0) r.se_cap = std::min(r.se_cap, h[64 + 8 * x + q]);
+        // How many stay queued on such an XCD depends on where the dispatcher's round-robin over the shader engines stands when the kernel
+        // starts: blocks are dealt to the engines in turn and the queue stops at the first block that does not fit, i.e. when the engine with
+        // the taken CU (capacity se_cap) is offered its (se_cap + 1)-th block -- after n_se * se_cap + (0 .. n_se - 1) blocks: 56 .. 59 of 64 on
+        // the MI355X (59 in a fresh process, 56-58 when the first solver is measured at the end of a config-4 engine's creation).  The rule takes
+        // the worst case of that geometry, which a later launch may meet whatever this one saw.
+        const int leave = r.queued_max > 0 ? std::max(r.queued_max, r.dealt - r.n_se * std::min(r.se_cap, r.dealt)) : 0;
+        r.keep = leave > 0 && r.n_xcd > 0 && grid % r.n_xcd == 0 && r.dealt > leave ? r.n_xcd * (r.dealt - leave) : 0;
         r.valid = true;
     }
     (void)hipGetLastError();

@@ -199,14 +199,15 @@ def test_keep_rule_is_derived_from_measured_residency():
     lib = engine.load_library()
     out = (C.c_int * 8)()
     assert lib.jaicov_debug_flow_residency(out) == 0
-    valid, n_xcd, n_se, dealt, resident, queued, keep, _ = list(out)
-    assert valid == 1 and n_xcd >= 1 and n_se >= 1 and dealt >= resident > 0 and queued == dealt - resident
-    leave = max(2 * n_se, queued + n_se - 1) if queued > 0 else 0
+    valid, n_xcd, n_se, dealt, resident, queued, keep, se_cap = list(out)
+    assert valid == 1 and n_xcd >= 1 and n_se >= 1 and dealt >= resident > 0 and queued == dealt - resident and se_cap >= 1
+    # the worst case of the geometry: the queue of such an XCD stops when the shader engine with the taken CU is offered one block too many
+    leave = max(queued, dealt - n_se * min(se_cap, dealt)) if queued > 0 else 0
     assert keep == (n_xcd * (dealt - leave) if leave and dealt > leave else 0)
     if (n_xcd, n_se, dealt) == (8, 4, 64):          # the MI355X: 59 of 64 resident on an XCD whose reserved CU is taken (15 + 15 + 15 + 14), 5 queued
-        # (59 / 5 / 448 in a process whose first dataflow solver is measured alone; 56-57 / 7-8 / 424-432 when the measurement of that solver
-        # ran at the end of a config-4 engine's creation: the rule follows the measurement either way)
-        assert 55 <= resident <= 59 and 416 <= keep <= 448
+        # (59 / 5 in a fresh process, 56-58 / 6-8 when the first solver was measured at the end of a config-4 engine's creation: the dispatcher's
+        # round-robin over the shader engines stood elsewhere; the rule is the worst case, 64 - 4 x 14 = 8 leave, whatever was seen)
+        assert 56 <= resident <= 59 and se_cap == 14 and keep == 448
 
 
 def test_dense_not_spd_reports_singular():
