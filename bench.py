@@ -182,9 +182,9 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            # The communicator is created AFTER the engine and without device_id (lazy): created before the engine's
-            # streams it slowed the engine's multi-stream factorisation by 25 % on this stack (scripts/dist_ab.py:
-            # 30.1 -> 38.4 ms with world size 1), created afterwards it does not.
+            # The communicator is created AFTER the engine and without device_id (lazy).  Through round 4 the other order slowed the
+            # factorisation by 25 % (30.1 -> 38.4 ms, world size 1): hardware-queue oversubscription; with one
+            # CU-masked queue per engine either order gives the same time (profiles/r05_c_dist_ab.log).  The order is kept.
             dist.init_process_group("nccl")
             warm = torch.zeros(1, dtype=torch.float64, device=torch.device("cuda", local))
             dist.all_reduce(warm)
