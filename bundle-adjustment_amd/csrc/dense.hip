@@ -972,25 +972,27 @@ hipError_t DenseSolver::init(hipStream_t s, int n_padded, bool with_inverse, boo
     const int flow_from = getenv("JAICOV_FLOW_MIN_BLOCKS") ? atoi(getenv("JAICOV_FLOW_MIN_BLOCKS")) : 12;      // (the tests lower it)
     const bool flow_wanted = factor_form() != FACTOR_STREAMS && nfact / 128 >= flow_from;
     borrowed_streams = share != nullptr && share->owns && !share->borrowed_streams && share->pstream != nullptr;
+    own_ustream = own_dstream = false;
     if (borrowed_streams) {
         pstream = share->pstream;
-        // reserved CUs as below; what the other solver does not hold is acquired here and then is this solver's own to release
-        ustream = share->ustream;
-        dstream = share->dstream;
-        own_ustream = own_dstream = false;
     } else {
         pstream = stream_acquire(STREAM_HIGH_PRIORITY);
         if (!pstream) return hipErrorUnknown;
-        own_ustream = own_dstream = false;
     }
     {
         // reserved CUs: CU 31 of every XCD for the diagonal blocks, the other 31 for the trailing updates (stream_acquire).  The masked
         // stream of the trailing updates is only held by a solver that factorises by the stream-scheduled form: the dataflow form
         // (flow_wanted) launches its tile kernel on the ordinary stream, and every CU-masked stream is a hardware queue (dense.h).
+        // A masked stream the other solver of the engine holds is used (only where this solver needs one); what it does not hold is
+        // acquired here and is then this solver's own to release.
         if (nfact >= 2048 || flow_wanted) {
             reserved_cus = 8;
+            dstream = borrowed_streams ? share->dstream : nullptr;
             if (!dstream) { dstream = stream_acquire(STREAM_DIAGONAL_CUS); own_dstream = dstream != nullptr; }
-            if (!flow_wanted && !ustream) { ustream = stream_acquire(STREAM_UPDATE_CUS); own_ustream = ustream != nullptr; }
+            if (!flow_wanted) {
+                ustream = borrowed_streams ? share->ustream : nullptr;
+                if (!ustream) { ustream = stream_acquire(STREAM_UPDATE_CUS); own_ustream = ustream != nullptr; }
+            }
             if (!dstream || (!flow_wanted && !ustream)) {
                 if (own_ustream) stream_release(STREAM_UPDATE_CUS, ustream);
                 if (own_dstream) stream_release(STREAM_DIAGONAL_CUS, dstream);
